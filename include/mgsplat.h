@@ -1,0 +1,164 @@
+/*
+ * mgsplat.h -- C ABI of libmgsplat.so, the MI355X (gfx950) Gaussian-splatting hot path.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it replaces.
+ *   RAST = third_party/gaussian-splatting/submodules/diff-gaussian-rasterization  (reference tree)
+ *   MG   = agents/manigaussian_bc                                                 (reference tree)
+ *
+ * Reference FFI today (pybind11, torch types): RAST/ext.cpp:15-19 exports
+ *   rasterize_gaussians           -> RasterizeGaussiansCUDA          (RAST/rasterize_points.cu:35-128)
+ *   rasterize_gaussians_backward  -> RasterizeGaussiansBackwardCUDA  (RAST/rasterize_points.cu:130-225)
+ *   mark_visible                  -> markVisible                     (RAST/rasterize_points.cu:227-246)
+ * which wrap CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+ * (RAST/cuda_rasterizer/rasterizer.h:20-92).
+ *
+ * Differences that the C ABI forces, all documented in INTEGRATION.md:
+ *   - no torch types: plain device pointers + sizes; the CALLER owns every buffer (outputs and the
+ *     three opaque workspaces geom/binning/img that the reference grows through a std::function
+ *     callback, RAST/rasterize_points.cu:27-33).  Sizes come from mgs_*_bytes().
+ *   - the reference's forward is split in two calls because the binning workspace is sized by
+ *     num_rendered, which the reference reads back mid-call (RAST/cuda_rasterizer/rasterizer_impl.cu:284).
+ *   - every call takes an explicit hipStream_t (the reference uses the legacy default stream).
+ *   - F (feature channels) is a run-time value; the reference fixes it at compile time
+ *     (RAST/cuda_rasterizer/config.h:16).
+ * All tensors are contiguous row-major float32 unless noted, on the device the stream belongs to.
+ * All functions return 0 on success, <0 on error (message via mgs_last_error(), thread-local).
+ */
+#ifndef MGSPLAT_H_
+#define MGSPLAT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_ABI_VERSION 1
+
+/* error codes */
+#define MGS_OK 0
+#define MGS_ERR_INVALID_ARG (-1)   /* bad shape / null pointer / unsupported F */
+#define MGS_ERR_HIP (-2)           /* a HIP runtime call or (debug=1) a kernel failed */
+#define MGS_ERR_WORKSPACE (-3)     /* a caller-provided workspace is too small */
+#define MGS_ERR_NON_RGB (-4)       /* reference: "For non-RGB, provide precomputed Gaussian colors!" */
+
+#define MGS_MAX_FEATURE_CHANNELS 64
+
+typedef void* mgs_stream_t; /* hipStream_t */
+
+/* Per-view configuration + inputs shared by forward and backward.
+ * Mirrors the argument lists of Rasterizer::forward / ::backward (RAST/cuda_rasterizer/rasterizer.h:35-91)
+ * and the fields of GaussianRasterizationSettings (RAST/diff_gaussian_rasterization/__init__.py:166-179). */
+typedef struct MgsRasterArgs {
+  int32_t P;               /* number of Gaussians (means3D.size(0))                                   */
+  int32_t D;               /* active SH degree (settings.sh_degree)                                   */
+  int32_t M;               /* SH coefficients per Gaussian (sh.size(1)), 0 when colors_precomp given  */
+  int32_t F;               /* feature channels (language_feature.size(1)); ignored if !include_feature */
+  int32_t W, H;            /* image size                                                              */
+  float tanfovx, tanfovy;  /* may be NEGATIVE (PyRep focal convention)           */
+  float scale_modifier;
+  int32_t prefiltered;     /* reference traps the device if a culled point shows up; here: error flag */
+  int32_t debug;           /* 1: synchronise + check after every stage (RAST auxiliary.h:166-173)     */
+  int32_t include_feature;
+  const float* background;      /* [3]                                                                */
+  const float* means3D;         /* [P,3]                                                              */
+  const float* shs;             /* [P,M,3] or NULL                                                    */
+  const float* colors_precomp;  /* [P,3]  or NULL (exactly one of shs / colors_precomp)               */
+  const float* language_feature;/* [P,F]  or NULL when !include_feature                               */
+  const float* opacities;       /* [P,1]  (forward only; backward reads it from the geom workspace)   */
+  const float* scales;          /* [P,3]  or NULL                                                     */
+  const float* rotations;       /* [P,4]  or NULL (r,x,y,z), used un-normalised like the reference    */
+  const float* cov3D_precomp;   /* [P,6]  or NULL (exactly one of scales+rotations / cov3D_precomp)   */
+  const float* viewmatrix;      /* [16] transposed world->view, m[col*4+row]                          */
+  const float* projmatrix;      /* [16] transposed full projection                                    */
+  const float* campos;          /* [3]                                                                */
+  /* opaque workspaces, caller-allocated device memory (uint8 tensors in the reference) */
+  void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M)            */
+  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H)      */
+  void* img;     size_t img_bytes;      /* >= mgs_img_bytes(W, H)             */
+} MgsRasterArgs;
+
+int mgs_abi_version(void);
+const char* mgs_last_error(void);
+
+/* Tuning / A-B switches (key names in DESIGN.md); returns <0 for an unknown key. */
+int mgs_set_option(const char* key, int value);
+int mgs_get_option(const char* key);
+
+/* Workspace sizes.  Replace required<GeometryState/ImageState/BinningState>()
+ * (RAST/cuda_rasterizer/rasterizer_impl.h:65-72, rasterizer_impl.cu:155-194). */
+size_t mgs_geom_bytes(int P, int M);
+size_t mgs_img_bytes(int W, int H);
+size_t mgs_binning_bytes(int R, int W, int H);
+size_t mgs_backward_scratch_bytes(int P, int M, int F);
+
+/* Forward, stage 1: preprocess + tile-count scan (K2, K3 of SURVEY.md 2b).
+ * Replaces the first half of Rasterizer::forward (RAST/cuda_rasterizer/rasterizer_impl.cu:198-284).
+ * Writes radii[P] (int32) and the geom workspace; *num_rendered (HOST int) receives the number of
+ * (Gaussian, tile) instances -- this call synchronises the stream once, exactly where the reference
+ * does its blocking cudaMemcpy (rasterizer_impl.cu:284). */
+int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
+                                     mgs_stream_t stream);
+
+/* Forward, stage 2: duplicate-with-keys, radix sort, tile ranges, alpha-composite render (K4-K7).
+ * Replaces rasterizer_impl.cu:286-355.  radii: the [P] int32 array stage 1 wrote.  out_color [3,H,W];
+ * out_feature [F,H,W] (untouched if !include_feature).  Both are fully written (no pre-zeroing needed). */
+int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
+                                 float* out_color, float* out_feature, mgs_stream_t stream);
+
+/* Backward (K8-K10).  Replaces Rasterizer::backward (rasterizer_impl.cu:359-463) and the output
+ * allocation of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:167-184).  Every non-NULL output
+ * is fully written (zero where the reference leaves its zero-initialised value).
+ *   dL_dout_color [3,H,W], dL_dout_feature [F,H,W] (NULL if !include_feature)
+ *   dL_dmeans2D [P,3] (NDC units, z = 0), dL_dopacity [P,1], dL_dcolors [P,3], dL_dfeature [P,F],
+ *   dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4],
+ *   dL_dconic [P,4] (optional, may be NULL; reference keeps it internal).
+ * scratch: >= mgs_backward_scratch_bytes(P, M, F) device bytes, contents undefined on entry. */
+int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
+                           const float* dL_dout_color, const float* dL_dout_feature, float* dL_dmeans2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dfeature,
+                           float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                           float* dL_drotations, void* scratch, size_t scratch_bytes, mgs_stream_t stream);
+
+/* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153).  present: uint8 [P] (torch.bool). */
+int mgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, mgs_stream_t stream);
+
+/* ---- deformation field: fused input assembly and apply epilogue (MG/models_embed.py:255-304) ----
+ * dyna_input[n, :] = cat(point_latent[n,0:DL], xyz[n,3], f_dc[n,3], f_rest[n,9], rot[n,4], scale[n,3],
+ *                        opacity[n,1], (feature[n,3] iff feature != NULL), PE(canon_xyz[n])[39] or z_feature,
+ *                        action[0, 0:DA] broadcast)                         (models_embed.py:258-287)
+ * z_feature is passed precomputed ([N, DZ], models_embed.py:208-213); sh is [N,4,3] = (f_dc, f_rest).
+ * Row stride of out = DL + 23 + (feature?3:0) + DZ + DA. */
+int mgs_deform_assemble_forward(int N, int DL, int DZ, int DA, const float* point_latent,
+                                const float* xyz, const float* sh, const float* rot, const float* scale,
+                                const float* opacity, const float* feature, const float* z_feature,
+                                const float* action, float* out, mgs_stream_t stream);
+/* Gradient of the assembly: only point_latent and z_feature receive gradient (everything else is
+ * .detach()ed in the reference).  g_out [N, stride] -> g_point_latent [N,DL], g_z_feature [N,DZ]. */
+int mgs_deform_assemble_backward(int N, int DL, int DZ, int DA, int has_feature, const float* g_out,
+                                 float* g_point_latent, float* g_z_feature, mgs_stream_t stream);
+/* next.xyz = xyz + delta[:,0:3]; next.rot = normalize(rot + delta[:,3:7])   (models_embed.py:295-299) */
+int mgs_deform_apply_forward(int N, const float* xyz, const float* rot, const float* delta /*[N,7]*/,
+                             float* xyz_out, float* rot_out, mgs_stream_t stream);
+/* g_delta [N,7] from g_xyz_out [N,3], g_rot_out [N,4] (xyz, rot are detached: no other gradient). */
+int mgs_deform_apply_backward(int N, const float* rot, const float* delta, const float* g_xyz_out,
+                              const float* g_rot_out, float* g_delta, mgs_stream_t stream);
+
+/* Per-stage device timing (hipEvents on the caller's stream), enabled with
+ * mgs_set_option("profile", 1) (render backward only) or 2 (every stage).  mgs_profile_read waits for the
+ * recorded events, writes the summed milliseconds and launch counts per stage ([mgs_profile_num_stages()]),
+ * and recycles the events when reset != 0. */
+int mgs_profile_num_stages(void);
+const char* mgs_profile_stage_name(int stage);
+int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
+
+/* Device self-test of the wave64 cross-lane primitives used by the render kernels (DPP rotations,
+ * v_permlane16/32_swap butterflies).  Returns 0 if every primitive matches its definition. */
+int mgs_selftest(mgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGSPLAT_H_ */

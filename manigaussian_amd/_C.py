@@ -1,0 +1,208 @@
+"""The three functions the reference's pybind module `diff_gaussian_rasterization._C` exports
+(RAST/ext.cpp:15-19), with the same names, argument order and return tuples, implemented over the
+C ABI of libmgsplat.so.  RAST = third_party/gaussian-splatting/submodules/diff-gaussian-rasterization.
+
+torch is plumbing here: it owns device memory (outputs + the three opaque byte workspaces that the
+reference also returns as uint8 tensors) and supplies the current HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_F32 = torch.float32
+
+
+def _padded_F(F: int) -> int:
+    for s in _lib.SUPPORTED_F:
+        if F <= s:
+            return s
+    raise RuntimeError(f"language feature width {F} > {_lib.SUPPORTED_F[-1]} is not supported")
+
+
+def _ptr(t):
+    return None if (t is None or t.numel() == 0) else t.data_ptr()
+
+
+def _f32c(t, name, dev):
+    """contiguous float32 on dev; empty tensors pass through (they become NULL pointers, like the
+    reference's .data<float>() of an empty tensor)."""
+    if t.numel() == 0:
+        return t
+    if t.dtype != _F32:
+        raise RuntimeError(f"expected scalar type Float but found {t.dtype} for {name}")
+    if t.device != dev:
+        raise RuntimeError(f"{name} is on {t.device} but means3D is on {dev}")
+    return t.contiguous()
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefiltered, debug, include_feature,
+               background, means3D, sh, colors, language_feature, opacity, scales, rotations, cov3D_precomp,
+               viewmatrix, projmatrix, campos, geom, binning, img):
+    a.P, a.D, a.M, a.F, a.W, a.H = P, D, M, F, W, H
+    a.tanfovx, a.tanfovy, a.scale_modifier = tanfovx, tanfovy, scale_modifier
+    a.prefiltered, a.debug, a.include_feature = int(bool(prefiltered)), int(bool(debug)), int(bool(include_feature))
+    a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors)
+    a.language_feature = _ptr(language_feature) if include_feature else None
+    a.opacities, a.scales, a.rotations, a.cov3D_precomp = _ptr(opacity), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+    a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
+    a.geom, a.geom_bytes = _ptr(geom), 0 if geom is None else geom.numel()
+    a.binning, a.binning_bytes = _ptr(binning), 0 if binning is None else binning.numel()
+    a.img, a.img_bytes = _ptr(img), 0 if img is None else img.numel()
+
+
+def rasterize_gaussians(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                        degree, campos, prefiltered, debug, include_feature):
+    """RasterizeGaussiansCUDA (RAST/rasterize_points.cu:35-128).
+    Returns (num_rendered, out_color [3,H,W], out_language_feature [F,H,W] or [1], radii [P] int32,
+             geomBuffer, binningBuffer, imgBuffer)."""
+    L = _lib.lib()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
+    if not means3D.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a HIP device; "
+                           "there is no CPU path")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    means3D = _f32c(means3D, "means3D", dev)
+    background = _f32c(background, "background", dev)
+    colors = _f32c(colors, "colors_precomp", dev)
+    opacity = _f32c(opacity, "opacities", dev)
+    scales = _f32c(scales, "scales", dev)
+    rotations = _f32c(rotations, "rotations", dev)
+    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp", dev)
+    viewmatrix = _f32c(viewmatrix, "viewmatrix", dev)
+    projmatrix = _f32c(projmatrix, "projmatrix", dev)
+    campos = _f32c(campos, "campos", dev)
+    sh = _f32c(sh, "sh", dev)
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    include_feature = bool(include_feature)
+    F = F_user = 0
+    if include_feature:
+        if language_feature.ndimension() != 2 or language_feature.size(0) != P:
+            raise RuntimeError("language_feature_precomp must have dimensions (num_points, F)")
+        language_feature = _f32c(language_feature, "language_feature_precomp", dev)
+        F_user = int(language_feature.size(1))
+        F = _padded_F(F_user)
+        if F != F_user:  # feature widths that are not compiled in: zero channels change nothing
+            language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+
+    with torch.cuda.device(dev):
+        out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
+        out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
+            torch.zeros((1,), dtype=_F32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        if P == 0:  # rasterize_points.cu:92: empty workspaces, zero images
+            out_color.zero_()
+            out_feat.zero_()
+            e = torch.empty((0,), **u8)
+            return 0, out_color, out_feat[:F_user] if include_feature else out_feat, radii, e, e.clone(), e.clone()
+        geom = torch.empty((L.mgs_geom_bytes(P, M),), **u8)
+        img = torch.empty((L.mgs_img_bytes(W, H),), **u8)
+        a = _lib.MgsRasterArgs()
+        kw = dict(P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
+                  scale_modifier=float(scale_modifier), prefiltered=prefiltered, debug=debug,
+                  include_feature=include_feature, background=background, means3D=means3D, sh=sh, colors=colors,
+                  language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
+                  cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos)
+        _fill_args(a, geom=geom, binning=None, img=img, **kw)
+        stream = _stream(dev)
+        nr = ctypes.c_int32(0)
+        _lib.check(L.mgs_rasterize_forward_preprocess(ctypes.byref(a), radii.data_ptr(), ctypes.byref(nr), stream),
+                   "rasterize_gaussians (preprocess)")
+        R = int(nr.value)
+        binning = torch.empty((L.mgs_binning_bytes(R, W, H),), **u8)
+        a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
+        _lib.check(L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(),
+                                                  _ptr(out_feat) if include_feature else None, stream),
+                   "rasterize_gaussians (render)")
+    if include_feature and F != F_user:
+        out_feat = out_feat[:F_user].contiguous()
+    return R, out_color, out_feat, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, language_feature, scales, rotations,
+                                 scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                 dL_dout_color, dL_dout_language_feature, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, debug, include_feature):
+    """RasterizeGaussiansBackwardCUDA (RAST/rasterize_points.cu:130-225).
+    Returns (dL_dmeans2D [P,3], dL_dcolors [P,3], dL_dlanguage_feature [P,F] or [1], dL_dopacity [P,1],
+             dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4])."""
+    L = _lib.lib()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    include_feature = bool(include_feature)
+    means3D = _f32c(means3D, "means3D", dev)
+    colors = _f32c(colors, "colors_precomp", dev)
+    scales = _f32c(scales, "scales", dev)
+    rotations = _f32c(rotations, "rotations", dev)
+    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp", dev)
+    sh = _f32c(sh, "sh", dev)
+    dL_dout_color = _f32c(dL_dout_color, "dL_dout_color", dev)
+    F = F_user = 0
+    if include_feature:
+        language_feature = _f32c(language_feature, "language_feature_precomp", dev)
+        F_user = int(language_feature.size(1))
+        F = _padded_F(F_user)
+        dL_dout_language_feature = _f32c(dL_dout_language_feature, "dL_dout_language_feature", dev)
+        if F != F_user:
+            language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+            dL_dout_language_feature = torch.cat(
+                [dL_dout_language_feature, dL_dout_language_feature.new_zeros((F - F_user, H, W))], 0)
+    with torch.cuda.device(dev):
+        opts = dict(dtype=_F32, device=dev)
+        g_means3D = torch.empty((P, 3), **opts)
+        g_means2D = torch.empty((P, 3), **opts)
+        g_colors = torch.empty((P, 3), **opts)
+        g_feat = torch.empty((P, F), **opts) if include_feature else torch.zeros((1,), **opts)
+        g_opacity = torch.empty((P, 1), **opts)
+        g_cov3D = torch.empty((P, 6), **opts)
+        g_sh = torch.empty((P, M, 3), **opts)
+        g_scales = torch.empty((P, 3), **opts)
+        g_rot = torch.empty((P, 4), **opts)
+        if P != 0:
+            scratch = torch.empty((L.mgs_backward_scratch_bytes(P, M, F),), dtype=torch.uint8, device=dev)
+            a = _lib.MgsRasterArgs()
+            _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
+                       scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
+                       include_feature=include_feature, background=_f32c(background, "background", dev),
+                       means3D=means3D, sh=sh, colors=colors, language_feature=language_feature, opacity=None,
+                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                       viewmatrix=_f32c(viewmatrix, "viewmatrix", dev), projmatrix=_f32c(projmatrix, "projmatrix", dev),
+                       campos=_f32c(campos, "campos", dev), geom=geomBuffer, binning=binningBuffer, img=imageBuffer)
+            _lib.check(L.mgs_rasterize_backward(
+                ctypes.byref(a), int(R), radii.data_ptr(), dL_dout_color.data_ptr(),
+                _ptr(dL_dout_language_feature) if include_feature else None, g_means2D.data_ptr(), None,
+                g_opacity.data_ptr(), g_colors.data_ptr(), _ptr(g_feat) if include_feature else None,
+                g_means3D.data_ptr(), g_cov3D.data_ptr(), _ptr(g_sh), g_scales.data_ptr(), g_rot.data_ptr(),
+                scratch.data_ptr(), scratch.numel(), _stream(dev)), "rasterize_gaussians_backward")
+    if include_feature and F != F_user:
+        g_feat = g_feat[:, :F_user].contiguous()
+    return g_means2D, g_colors, g_feat, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (RAST/rasterize_points.cu:227-246): bool [P], True where view-space z > 0.2."""
+    L = _lib.lib()
+    if not means3D.is_cuda:
+        raise RuntimeError("mark_visible needs tensors on a HIP device; there is no CPU path")
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            m = _f32c(means3D, "means3D", dev)
+            v = _f32c(viewmatrix, "viewmatrix", dev)
+            p = _f32c(projmatrix, "projmatrix", dev)
+            _lib.check(L.mgs_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr(),
+                                          _stream(dev)), "mark_visible")
+    return present

@@ -1,0 +1,9 @@
+"""manigaussian_amd -- MI355X-native (gfx950) Gaussian-splatting hot path of ManiGaussian.
+
+Scope: the differentiable tile rasterizer (RGB + feature channels, fwd+bwd) behind the
+reference's GaussianRasterizer / GaussianRasterizationSettings API, and the deformation-field per-Gaussian
+apply.  Native code: manigaussian_amd/csrc (HIP) -> libmgsplat.so, C ABI in include/mgsplat.h.
+"""
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians  # noqa: F401
+
+__version__ = "0.1.0"

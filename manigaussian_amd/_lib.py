@@ -1,0 +1,113 @@
+"""ctypes binding of libmgsplat.so (C ABI declared in include/mgsplat.h).
+
+There is no CPU fallback and no other backend: if the HIP library is missing or stale this module
+raises, loudly, at import of the ops (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C manigaussian_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
+ABI_VERSION = 1
+
+c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+c_i32 = ctypes.c_int32
+c_sz = ctypes.c_size_t
+
+# error codes (include/mgsplat.h)
+MGS_OK, MGS_ERR_INVALID_ARG, MGS_ERR_HIP, MGS_ERR_WORKSPACE, MGS_ERR_NON_RGB = 0, -1, -2, -3, -4
+
+SUPPORTED_F = (3, 4, 8, 16, 32, 64)
+
+
+class MgsRasterArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", c_i32), ("D", c_i32), ("M", c_i32), ("F", c_i32), ("W", c_i32), ("H", c_i32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("prefiltered", c_i32), ("debug", c_i32), ("include_feature", c_i32),
+        ("background", c_fp), ("means3D", c_fp), ("shs", c_fp), ("colors_precomp", c_fp),
+        ("language_feature", c_fp), ("opacities", c_fp), ("scales", c_fp), ("rotations", c_fp),
+        ("cov3D_precomp", c_fp), ("viewmatrix", c_fp), ("projmatrix", c_fp), ("campos", c_fp),
+        ("geom", c_fp), ("geom_bytes", c_sz), ("binning", c_fp), ("binning_bytes", c_sz),
+        ("img", c_fp), ("img_bytes", c_sz),
+    ]
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "mgs_abi_version": (ctypes.c_int, []),
+    "mgs_last_error": (ctypes.c_char_p, []),
+    "mgs_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "mgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
+    "mgs_geom_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "mgs_img_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mgs_backward_scratch_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mgs_rasterize_forward_preprocess": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp,
+                                                        ctypes.POINTER(c_i32), c_fp]),
+    "mgs_rasterize_forward_render": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp, c_fp, c_fp, c_fp]),
+    "mgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp] + [c_fp] * 12 +
+                               [c_fp, c_sz, c_fp]),
+    "mgs_mark_visible": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "mgs_deform_assemble_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [c_fp] * 10 + [c_fp]),
+    "mgs_deform_assemble_backward": (ctypes.c_int, [ctypes.c_int] * 5 + [c_fp] * 3 + [c_fp]),
+    "mgs_deform_apply_forward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 5 + [c_fp]),
+    "mgs_deform_apply_backward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 5 + [c_fp]),
+    "mgs_selftest": (ctypes.c_int, [c_fp]),
+    "mgs_profile_num_stages": (ctypes.c_int, []),
+    "mgs_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "mgs_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.c_int]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/mgsplat.h declares."""
+    return sorted(_EXPORTS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP library is not built. There is no fallback path; run "
+                "`make -C manigaussian_amd/csrc` (hipcc, gfx950) or __graft_entry__.build().")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (rt, at) in _EXPORTS.items():
+            fn = getattr(L, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = rt, at
+        v = L.mgs_abi_version()
+        if v != ABI_VERSION:
+            raise ImportError(f"libmgsplat ABI version {v} != expected {ABI_VERSION}; rebuild")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().mgs_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {last_error()} (code {rc})")
+
+
+def set_option(key: str, value: int):
+    check(lib().mgs_set_option(key.encode(), int(value)), "mgs_set_option")
+
+
+def get_option(key: str) -> int:
+    return lib().mgs_get_option(key.encode())
+
+
+def profile_read(reset: bool = True):
+    """{stage name: (total ms, launches)} from the library's hipEvent stage timers."""
+    L = lib()
+    n = L.mgs_profile_num_stages()
+    ms = (ctypes.c_double * n)()
+    cnt = (c_i32 * n)()
+    check(L.mgs_profile_read(ms, cnt, int(reset)), "mgs_profile_read")
+    return {L.mgs_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}

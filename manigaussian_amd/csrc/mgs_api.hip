@@ -1,0 +1,359 @@
+// mgs_api.hip -- the C ABI of libmgsplat.so (declared in include/mgsplat.h): argument validation,
+// workspace carving, stage sequencing on the caller's stream.  No torch, no global device state.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "mgs_common.h"
+
+namespace mgs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+Options& options() {
+  static Options o;
+  return o;
+}
+
+static bool supported_F(int F) {
+  switch (F) {
+    case 0: case 3: case 4: case 8: case 16: case 32: case 64: return true;
+    default: return false;
+  }
+}
+
+// ---- per-stage timing with hipEvents on the caller's stream (mgs_set_option("profile", 1|2)) ----
+enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_BWD_MEMSET, ST_RENDER_BWD,
+             ST_PREPROCESS_BWD, ST_COUNT };
+static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_with_keys", "radix_sort",
+                                                  "ranges_gather", "render_fwd", "bwd_memset", "render_bwd",
+                                                  "preprocess_bwd"};
+struct Profiler {
+  std::mutex mu;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> used[ST_COUNT];
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+static Profiler& profiler() { static Profiler p; return p; }
+
+struct StageTimer {  // RAII: records start now, stop at scope exit
+  int stage; hipStream_t stream; hipEvent_t e0 = nullptr, e1 = nullptr;
+  StageTimer(int st, hipStream_t s) : stage(st), stream(s) {
+    const int lvl = options().profile;
+    if (lvl == 0 || (lvl == 1 && st != ST_RENDER_BWD)) return;
+    Profiler& p = profiler();
+    std::lock_guard<std::mutex> lk(p.mu);
+    e0 = p.get(); e1 = p.get();
+    if (e0 && e1) hipEventRecord(e0, stream); else e0 = e1 = nullptr;
+  }
+  ~StageTimer() {
+    if (!e0) return;
+    hipEventRecord(e1, stream);
+    Profiler& p = profiler();
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.used[stage].push_back({e0, e1});
+  }
+};
+
+#define MGS_HIP(expr, what)                                                      \
+  do {                                                                           \
+    hipError_t _e = (expr);                                                      \
+    if (_e != hipSuccess) {                                                      \
+      set_error("%s failed: %s", what, hipGetErrorString(_e));                   \
+      return MGS_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+
+// debug=1: synchronise and check after a stage (RAST auxiliary.h:166-173 CHECK_CUDA)
+#define MGS_STAGE(expr, what, dbg, stream)                                       \
+  do {                                                                           \
+    MGS_HIP(expr, what);                                                         \
+    if (dbg) MGS_HIP(hipStreamSynchronize(stream), what " (debug sync)");        \
+  } while (0)
+
+static int check_common(const MgsRasterArgs* a) {
+  if (!a) { set_error("args is NULL"); return MGS_ERR_INVALID_ARG; }
+  if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad P/W/H (%d,%d,%d)", a->P, a->W, a->H); return MGS_ERR_INVALID_ARG; }
+  if (a->P > 0) {
+    if (!a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background) {
+      set_error("means3D/viewmatrix/projmatrix/campos/background must be non-NULL");
+      return MGS_ERR_INVALID_ARG;
+    }
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) {
+      // the reference hard-codes NUM_CHANNELS = 3; with neither it throws (rasterizer_impl.cu:245-248)
+      set_error(a->shs ? "both shs and colors_precomp given" : "For non-RGB, provide precomputed Gaussian colors!");
+      return a->shs ? MGS_ERR_INVALID_ARG : MGS_ERR_NON_RGB;
+    }
+    if (a->shs && a->M <= 0) { set_error("shs given but M <= 0"); return MGS_ERR_INVALID_ARG; }
+    if (a->shs && (a->D < 0 || (a->D + 1) * (a->D + 1) > a->M || a->D > 3)) {
+      set_error("sh_degree %d needs %d coefficients, M = %d (max degree 3)", a->D, (a->D + 1) * (a->D + 1), a->M);
+      return MGS_ERR_INVALID_ARG;
+    }
+    const bool sr = a->scales && a->rotations;
+    if (sr == (a->cov3D_precomp != nullptr) || (!sr && (a->scales || a->rotations))) {
+      set_error("provide exactly one of scales+rotations or cov3D_precomp");
+      return MGS_ERR_INVALID_ARG;
+    }
+    if (a->include_feature) {
+      if (!a->language_feature) { set_error("include_feature set but language_feature is NULL"); return MGS_ERR_INVALID_ARG; }
+      if (!supported_F(a->F) || a->F == 0) {
+        set_error("feature width F=%d not compiled in (supported: 3,4,8,16,32,64; pad to the next one)", a->F);
+        return MGS_ERR_INVALID_ARG;
+      }
+    }
+  }
+  return MGS_OK;
+}
+
+}  // namespace mgs
+
+using namespace mgs;
+
+extern "C" {
+
+int mgs_abi_version(void) { return MGS_ABI_VERSION; }
+const char* mgs_last_error(void) { return g_err; }
+
+int mgs_set_option(const char* key, int value) {
+  Options& o = options();
+  if (!strcmp(key, "tight_bins")) o.tight_bins = value;
+  else if (!strcmp(key, "bwd_reduce")) o.bwd_reduce = value;
+  else if (!strcmp(key, "fast_exp")) o.fast_exp = value;
+  else if (!strcmp(key, "profile")) o.profile = value;
+  else { set_error("unknown option %s", key); return MGS_ERR_INVALID_ARG; }
+  return MGS_OK;
+}
+int mgs_get_option(const char* key) {
+  Options& o = options();
+  if (!strcmp(key, "tight_bins")) return o.tight_bins;
+  if (!strcmp(key, "bwd_reduce")) return o.bwd_reduce;
+  if (!strcmp(key, "fast_exp")) return o.fast_exp;
+  if (!strcmp(key, "profile")) return o.profile;
+  set_error("unknown option %s", key);
+  return MGS_ERR_INVALID_ARG;
+}
+
+size_t mgs_geom_bytes(int P, int M) { size_t t; carve_geom(nullptr, P, M, &t); return t; }
+size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
+size_t mgs_binning_bytes(int R, int W, int H) { (void)W; (void)H; size_t t; carve_binning(nullptr, R, &t); return t; }
+size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
+
+int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
+                                     mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!num_rendered) { set_error("num_rendered is NULL"); return MGS_ERR_INVALID_ARG; }
+  *num_rendered = 0;
+  if (a->P == 0) return MGS_OK;  // rasterize_points.cu:92
+  if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
+  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M)) {
+    set_error("geom workspace too small: %zu < %zu", a->geom_bytes, mgs_geom_bytes(a->P, a->M));
+    return MGS_ERR_WORKSPACE;
+  }
+  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
+  FwdPreArgs p;
+  p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
+  p.tiles_x = (a->W + TILE - 1) / TILE; p.tiles_y = (a->H + TILE - 1) / TILE;
+  p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
+  p.focal_y = a->H / (2.0f * a->tanfovy);  // rasterizer_impl.cu:225-226
+  p.focal_x = a->W / (2.0f * a->tanfovx);
+  p.scale_modifier = a->scale_modifier;
+  p.prefiltered = a->prefiltered; p.tight_bins = options().tight_bins;
+  p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
+  p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
+  p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
+  MGS_HIP(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream), "memset flags");
+  { StageTimer t(ST_PREPROCESS, stream);
+    MGS_STAGE(launch_preprocess_fwd(p, g, radii, stream), "preprocess", a->debug, stream); }
+  { StageTimer t(ST_SCAN, stream);
+    MGS_STAGE(launch_scan(g, a->P, stream), "tile-count scan", a->debug, stream); }
+  // the one host read-back of the forward, where the reference has it (rasterizer_impl.cu:284)
+  uint32_t host[2] = {0, 0};
+  MGS_HIP(hipMemcpyAsync(&host[0], g.point_offsets + (a->P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
+          "num_rendered read-back");
+  MGS_HIP(hipMemcpyAsync(&host[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "flag read-back");
+  MGS_HIP(hipStreamSynchronize(stream), "stream sync");
+  if (host[1] & 1u) {
+    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");  // auxiliary.h:158
+    return MGS_ERR_INVALID_ARG;
+  }
+  *num_rendered = (int32_t)host[0];
+  return MGS_OK;
+}
+
+int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_t* radii, float* out_color,
+                                 float* out_feature, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!out_color) { set_error("out_color is NULL"); return MGS_ERR_INVALID_ARG; }
+  const size_t N = (size_t)a->W * a->H;
+  const int F = a->include_feature ? a->F : 0;
+  if (F > 0 && !out_feature) { set_error("out_feature is NULL"); return MGS_ERR_INVALID_ARG; }
+  if (a->P == 0) {  // rasterize_points.cu:70-92: zero-filled outputs, nothing launched
+    MGS_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream), "memset out_color");
+    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, F * N * sizeof(float), stream), "memset out_feature");
+    return MGS_OK;
+  }
+  if (R < 0 || !radii) { set_error("num_rendered < 0 or radii NULL"); return MGS_ERR_INVALID_ARG; }
+  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
+      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H)) {
+    set_error("workspace too small (geom %zu/%zu, img %zu/%zu, binning %zu/%zu)", a->geom_bytes,
+              mgs_geom_bytes(a->P, a->M), a->img_bytes, mgs_img_bytes(a->W, a->H), a->binning_bytes,
+              mgs_binning_bytes(R, a->W, a->H));
+    return MGS_ERR_WORKSPACE;
+  }
+  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
+  ImgView im = carve_img(a->img, a->W, a->H, nullptr);
+  BinView b = carve_binning(a->binning, R, nullptr);
+  const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
+  { StageTimer t(ST_DUPLICATE, stream);
+    MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, options().tight_bins, stream),
+              "duplicate_with_keys", a->debug, stream); }
+  { StageTimer t(ST_SORT, stream);
+    MGS_STAGE(launch_sort(b, R, tiles_x, tiles_y, stream), "radix sort", a->debug, stream); }
+  { StageTimer t(ST_RANGES, stream);
+    MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
+  RenderArgs r;
+  r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
+  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce;
+  r.bg = a->background;
+  r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
+  r.feats = a->language_feature;
+  { StageTimer t(ST_RENDER_FWD, stream);
+    MGS_STAGE(launch_render_fwd(r, b, im, out_color, out_feature, stream), "render forward", a->debug, stream); }
+  return MGS_OK;
+}
+
+int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* radii, const float* dL_dout_color,
+                           const float* dL_dout_feature, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
+                           float* dL_dcolors, float* dL_dfeature, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscales, float* dL_drotations, void* scratch, size_t scratch_bytes,
+                           mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (a->P == 0) return MGS_OK;  // rasterize_points.cu:186: empty gradient tensors
+  const int F = a->include_feature ? a->F : 0;
+  if (!radii || !dL_dout_color || !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D ||
+      !dL_dscales || !dL_drotations || (a->M > 0 && !dL_dsh) || (F > 0 && (!dL_dfeature || !dL_dout_feature))) {
+    set_error("backward: a required pointer is NULL");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if (!scratch || scratch_bytes < mgs_backward_scratch_bytes(a->P, a->M, F) || !a->geom ||
+      a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
+      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H)) {
+    set_error("backward: workspace too small");
+    return MGS_ERR_WORKSPACE;
+  }
+  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
+  ImgView im = carve_img(a->img, a->W, a->H, nullptr);
+  BinView b = carve_binning(a->binning, R, nullptr);
+  BwdScratch sc = carve_bwd(scratch, a->P, a->M, F, nullptr);
+  const size_t P = (size_t)a->P;
+  // accumulators the render backward adds into
+  // dL_dcolors is the gradient w.r.t. the per-Gaussian RGB whether it came from colors_precomp or from SH
+  // (the reference returns it in both cases, rasterize_points.cu:169,224)
+  float* dcol = dL_dcolors;
+  { StageTimer t(ST_BWD_MEMSET, stream);
+    MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * P * sizeof(float), stream), "memset acc8");
+    MGS_HIP(hipMemsetAsync(dcol, 0, 3 * P * sizeof(float), stream), "memset dL_dcolors");
+    if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature"); }
+  const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
+  if (R > 0) {
+    RenderArgs r;
+    r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
+    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce;
+    r.bg = a->background;
+    r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
+    r.feats = a->language_feature;
+    StageTimer t(ST_RENDER_BWD, stream);
+    MGS_STAGE(launch_render_bwd(r, b, im, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
+              "render backward", a->debug, stream);
+  }
+  BwdPreArgs p;
+  p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
+  p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
+  p.focal_y = a->H / (2.0f * a->tanfovy);
+  p.focal_x = a->W / (2.0f * a->tanfovx);
+  p.scale_modifier = a->scale_modifier;
+  p.means3D = a->means3D; p.shs = a->shs; p.scales = a->scales; p.rotations = a->rotations;
+  p.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
+  p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
+  p.radii = radii; p.clamped = g.clamped; p.acc8 = sc.acc8; p.dL_dcolor = dcol;
+  p.dL_dmeans2D = dL_dmeans2D; p.dL_dconic = dL_dconic; p.dL_dopacity = dL_dopacity; p.dL_dmeans3D = dL_dmeans3D;
+  p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh; p.dL_dscales = dL_dscales; p.dL_drot = dL_drotations;
+  { StageTimer t(ST_PREPROCESS_BWD, stream);
+    MGS_STAGE(launch_preprocess_bwd(p, stream), "preprocess backward", a->debug, stream); }
+  return MGS_OK;
+}
+
+int mgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P < 0) { set_error("P < 0"); return MGS_ERR_INVALID_ARG; }
+  if (P == 0) return MGS_OK;
+  if (!means3D || !viewmatrix || !projmatrix || !present) { set_error("mark_visible: NULL pointer"); return MGS_ERR_INVALID_ARG; }
+  MGS_HIP(launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, stream), "mark_visible");
+  return MGS_OK;
+}
+
+int mgs_profile_num_stages(void) { return ST_COUNT; }
+const char* mgs_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+int mgs_profile_read(double* total_ms, int32_t* counts, int reset) {
+  Profiler& p = profiler();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (int st = 0; st < ST_COUNT; st++) {
+    double sum = 0;
+    int n = 0;
+    for (auto& pr : p.used[st]) {
+      float ms = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        sum += ms;
+        n++;
+      }
+    }
+    if (total_ms) total_ms[st] = sum;
+    if (counts) counts[st] = n;
+    if (reset) {
+      for (auto& pr : p.used[st]) { p.pool.push_back(pr.first); p.pool.push_back(pr.second); }
+      p.used[st].clear();
+    }
+  }
+  return MGS_OK;
+}
+
+int mgs_selftest(mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int* d = nullptr;
+  MGS_HIP(hipMalloc(&d, sizeof(int)), "hipMalloc");
+  int h = 0;
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(int), stream);
+  if (e == hipSuccess) e = launch_selftest(d, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  hipFree(d);
+  MGS_HIP(e, "selftest");
+  if (h != 0) { set_error("wave64 primitive self-test failed, mask 0x%x", h); return h; }
+  return MGS_OK;
+}
+
+}  // extern "C"

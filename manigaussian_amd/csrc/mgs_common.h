@@ -1,0 +1,185 @@
+// mgs_common.h -- shared host/device definitions for libmgsplat (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mgsplat.h"
+
+namespace mgs {
+
+constexpr int TILE = 16;         // tile membership granularity: must stay 16 (RAST config.h:17-18)
+constexpr int SUB = 8;           // execution granularity: one wave64 per 8x8 pixel block
+constexpr int SUBS_PER_TILE = 4;
+constexpr int WAVE = 64;
+
+// ---- workspace carving (replaces obtain()/fromChunk, RAST rasterizer_impl.h:19-63) -------------
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
+
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+  size_t total() const { return align_up(off) + ALIGN; }
+};
+
+// Per-Gaussian state written by the forward preprocess (SoA).
+struct GeomView {
+  float* depths;            // [P]   view-space z
+  float2* means2D;          // [P]   pixel coordinates
+  float4* conic_opacity;    // [P]   conic.x, conic.y, conic.z, opacity
+  float2* cullext;          // [P]   half extents (px) of the bbox of {alpha >= 1/255}; <0: never visible
+  float* rgb;               // [3P]  SH -> RGB (unused with colors_precomp)
+  float* cov3D;             // [6P]
+  uint8_t* clamped;         // [P]   bit c set: SH colour channel c was clamped at 0
+  uint32_t* tiles_touched;  // [P]
+  uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched
+  uint32_t* flags;          // [4]   [0]: prefiltered violation
+  void* scan_temp;
+  size_t scan_temp_bytes;
+};
+
+struct ImgView {
+  float* final_T;       // [N]
+  uint32_t* n_contrib;  // [N]  1-based position in the tile list of the last blended entry
+  uint2* ranges;        // [T]
+};
+
+struct BinView {
+  uint64_t* keys_unsorted;  // [R]
+  uint64_t* keys;           // [R]
+  uint32_t* vals_unsorted;  // [R]
+  uint32_t* point_list;     // [R]  sorted Gaussian ids
+  float4* inst;             // [2R] sorted packed records {x,y,cx,cy}{cz,opacity,hx,hy}
+  void* sort_temp;
+  size_t sort_temp_bytes;
+};
+
+size_t scan_temp_bytes(int P);
+size_t sort_temp_bytes(int R);
+
+inline GeomView carve_geom(void* p, int P, int M, size_t* total) {
+  Carver c(p);
+  GeomView g;
+  size_t Pa = P > 0 ? (size_t)P : 1;
+  g.depths = c.take<float>(Pa);
+  g.means2D = c.take<float2>(Pa);
+  g.conic_opacity = c.take<float4>(Pa);
+  g.cullext = c.take<float2>(Pa);
+  g.rgb = c.take<float>(3 * Pa);
+  g.cov3D = c.take<float>(6 * Pa);
+  g.clamped = c.take<uint8_t>(Pa);
+  g.tiles_touched = c.take<uint32_t>(Pa);
+  g.point_offsets = c.take<uint32_t>(Pa);
+  g.flags = c.take<uint32_t>(4);
+  g.scan_temp_bytes = scan_temp_bytes((int)Pa);
+  g.scan_temp = c.take<char>(g.scan_temp_bytes);
+  (void)M;
+  if (total) *total = c.total();
+  return g;
+}
+
+inline ImgView carve_img(void* p, int W, int H, size_t* total) {
+  Carver c(p);
+  ImgView v;
+  size_t N = (size_t)W * H;
+  size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  v.final_T = c.take<float>(N ? N : 1);
+  v.n_contrib = c.take<uint32_t>(N ? N : 1);
+  v.ranges = c.take<uint2>(T ? T : 1);
+  if (total) *total = c.total();
+  return v;
+}
+
+inline BinView carve_binning(void* p, int R, size_t* total) {
+  Carver c(p);
+  BinView b;
+  size_t Ra = R > 0 ? (size_t)R : 1;
+  b.keys_unsorted = c.take<uint64_t>(Ra);
+  b.keys = c.take<uint64_t>(Ra);
+  b.vals_unsorted = c.take<uint32_t>(Ra);
+  b.point_list = c.take<uint32_t>(Ra);
+  b.inst = c.take<float4>(2 * Ra);
+  b.sort_temp_bytes = sort_temp_bytes((int)Ra);
+  b.sort_temp = c.take<char>(b.sort_temp_bytes);
+  if (total) *total = c.total();
+  return b;
+}
+
+// Backward scratch: per-Gaussian accumulators the render backward adds into.
+struct BwdScratch {
+  float* acc8;      // [P][8]: dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, -, -
+};
+inline BwdScratch carve_bwd(void* p, int P, int M, int F, size_t* total) {
+  Carver c(p);
+  BwdScratch s;
+  size_t Pa = P > 0 ? (size_t)P : 1;
+  s.acc8 = c.take<float>(8 * Pa);
+  (void)M; (void)F;
+  if (total) *total = c.total();
+  return s;
+}
+
+// ---- run-time options (mgs_set_option) ----------------------------------------------------------
+struct Options {
+  int tight_bins = 0;      // 1: drop (Gaussian,tile) instances whose alpha>=1/255 footprint misses the tile
+  int bwd_reduce = 1;      // 0: shuffle reference reduction, 1: butterfly (permlane swap + DPP)
+  int fast_exp = 0;        // 1: v_exp_f32 based exp in the render kernels
+  int profile = 0;         // 0: off, 1: hipEvents around the render backward only, 2: around every stage
+};
+Options& options();
+
+// ---- launch wrappers (one per .hip translation unit) --------------------------------------------
+void set_error(const char* fmt, ...);
+
+struct FwdPreArgs {
+  int P, D, M, W, H, tiles_x, tiles_y;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int prefiltered, tight_bins;
+  const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+  const float *viewmatrix, *projmatrix, *campos;
+};
+hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s);
+hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
+hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
+                            int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);
+hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s);
+hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im, int R, hipStream_t s);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj,
+                               uint8_t* present, hipStream_t s);
+
+struct RenderArgs {
+  int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, bwd_reduce;
+  const float* bg;
+  const float* colors;   // [P,3] colors_precomp or geom.rgb
+  const float* feats;    // [P,F]
+};
+hipError_t launch_render_fwd(const RenderArgs& r, const BinView& b, const ImgView& im, float* out_color,
+                             float* out_feat, hipStream_t s);
+hipError_t launch_render_bwd(const RenderArgs& r, const BinView& b, const ImgView& im, const float* dL_dcolor_px,
+                             const float* dL_dfeat_px, float* acc8, float* dL_dcolors, float* dL_dfeat,
+                             hipStream_t s);
+
+struct BwdPreArgs {
+  int P, D, M, W, H;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  const float *means3D, *shs, *scales, *rotations, *cov3D, *viewmatrix, *projmatrix, *campos;
+  const int32_t* radii;
+  const uint8_t* clamped;
+  const float* acc8;
+  const float* dL_dcolor;  // [P,3] gradient w.r.t. the per-Gaussian RGB
+  float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drot;
+};
+hipError_t launch_preprocess_bwd(const BwdPreArgs& a, hipStream_t s);
+
+hipError_t launch_selftest(int* result_dev, hipStream_t s);
+
+}  // namespace mgs

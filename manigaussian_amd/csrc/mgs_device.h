@@ -1,0 +1,116 @@
+// mgs_device.h -- wave64 cross-lane primitives for gfx950 (CDNA4).  Device code only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mgs {
+
+// ---- DPP controls (gfx9 encoding) -----------------------------------------------------------------
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR8 = 0x128;       // row_ror:8  (lane l <- lane (l+8)%16 of its row == l^8)
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane l <- lane 7-(l%8) of its 8-lane half
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ float bcast_lane(float v, int j /*wave-uniform*/) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ uint32_t bcast_lane_u32(uint32_t v, int j) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+}
+
+// v_permlane32_swap x, y: lanes 32..63 of x <-> lanes 0..31 of y.
+__device__ __forceinline__ void swap32(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(y), false, false);
+  x = __int_as_float(r[0]);
+  y = __int_as_float(r[1]);
+}
+// v_permlane16_swap x, y: odd rows (16-lane groups 1,3) of x <-> even rows (0,2) of y.
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
+  x = __int_as_float(r[0]);
+  y = __int_as_float(r[1]);
+}
+
+// One halving step of the transposing butterfly at lane distance D.  Returns a register whose lanes
+// with bit log2(D) == 0 hold x[self] + x[partner] and whose other lanes hold y[self] + y[partner].
+template <int D>
+__device__ __forceinline__ float bfly_halve(float x, float y, int lane) {
+  if constexpr (D == 32) {
+    swap32(x, y);
+    return x + y;
+  } else if constexpr (D == 16) {
+    swap16(x, y);
+    return x + y;
+  } else {
+    const bool hi = (lane & D) != 0;
+    const float keep = hi ? y : x;
+    const float send = hi ? x : y;
+    if constexpr (D == 8) return keep + dpp_mov<DPP_ROW_ROR8>(send);
+    else if constexpr (D == 4) return keep + dpp_mov<DPP_ROW_HALF_MIRROR>(send);
+    else if constexpr (D == 2) return keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    else return keep + dpp_mov<DPP_QUAD_XOR1>(send);
+  }
+}
+
+// All-reduce step at distance D (every lane ends with self + partner).
+template <int D>
+__device__ __forceinline__ float bfly_all(float v) {
+  if constexpr (D == 32) {
+    float y = v;
+    swap32(v, y);
+    return v + y;
+  } else if constexpr (D == 16) {
+    float y = v;
+    swap16(v, y);
+    return v + y;
+  } else if constexpr (D == 8) return v + dpp_mov<DPP_ROW_ROR8>(v);
+  else if constexpr (D == 4) return v + dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  else if constexpr (D == 2) return v + dpp_mov<DPP_QUAD_XOR2>(v);
+  else return v + dpp_mov<DPP_QUAD_XOR1>(v);
+}
+
+// Transposing butterfly reduction of N (power of two, <= 64) per-lane values over the 64 lanes.
+// On return a[0] in lane l holds the wave-wide sum of value index  (l >> (6 - log2 N)) & (N-1);
+// the lanes whose low (6 - log2 N) bits are zero are the canonical owners.
+template <int N, int D = 32>
+__device__ __forceinline__ void bfly_reduce(float* a, int lane) {
+  if constexpr (D >= 1) {
+    if constexpr (N == 1) {
+      a[0] = bfly_all<D>(a[0]);
+      bfly_reduce<1, D / 2>(a, lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N / 2; i++) a[i] = bfly_halve<D>(a[i], a[i + N / 2], lane);
+      bfly_reduce<N / 2, D / 2>(a, lane);
+    }
+  }
+}
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
+constexpr int next_pow2(int n) { int p = 1; while (p < n) p *= 2; return p; }
+
+// Reference (slow) all-lanes sum through ds_bpermute shuffles -- used to validate the butterfly.
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+}  // namespace mgs

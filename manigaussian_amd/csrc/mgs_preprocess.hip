@@ -1,0 +1,434 @@
+// mgs_preprocess.hip -- per-Gaussian kernels: forward preprocess (K2), fused backward preprocess
+// (K9 + K10 in one pass), frustum marking (K1).  One thread per Gaussian, streaming, HBM-bound.
+//
+// What is computed follows the reference (RAST = third_party/gaussian-splatting/submodules/
+// diff-gaussian-rasterization): forward.cu:156-257 (preprocessCUDA), :75-114 (computeCov2D),
+// :119-153 (computeCov3D), :21-72 (SH -> RGB); backward.cu:144-274 (computeCov2DCUDA),
+// :346-396 (preprocessCUDA bwd), :20-139 (SH bwd), :278-341 (cov3D bwd).  How it is computed is
+// not: plain scalar algebra on registers (glm is not used), K9 and K10 fused so every per-Gaussian
+// array is touched once, outputs written unconditionally so no pre-zeroing pass is needed.
+#include "mgs_common.h"
+
+namespace mgs {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                        -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                        0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                        -0.5900435899266435f};
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 ld3(const float* p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+// The projection of the mean: shared by forward and backward (recompute instead of storing).
+struct ViewCov {
+  float tx, ty, tz;     // clamped view-space mean (forward.cu:83-88)
+  float txtz, tytz;     // unclamped ratios (backward.cu:173-176)
+  float a[3], b[3];     // rows of T = W*J that matter: T[0][r], T[1][r] in glm indexing
+};
+
+__device__ __forceinline__ ViewCov view_cov(V3 mean, const float* __restrict__ vm, float fx, float fy,
+                                            float tanx, float tany) {
+  ViewCov o;
+  float tx = vm[0] * mean.x + vm[4] * mean.y + vm[8] * mean.z + vm[12];
+  float ty = vm[1] * mean.x + vm[5] * mean.y + vm[9] * mean.z + vm[13];
+  float tz = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
+  const float limx = 1.3f * tanx, limy = 1.3f * tany;
+  o.txtz = tx / tz;
+  o.tytz = ty / tz;
+  tx = fminf(limx, fmaxf(-limx, o.txtz)) * tz;
+  ty = fminf(limy, fmaxf(-limy, o.tytz)) * tz;
+  o.tx = tx; o.ty = ty; o.tz = tz;
+  const float j00 = fx / tz, j02 = -(fx * tx) / (tz * tz);
+  const float j11 = fy / tz, j12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    o.a[r] = vm[4 * r + 0] * j00 + vm[4 * r + 2] * j02;
+    o.b[r] = vm[4 * r + 1] * j11 + vm[4 * r + 2] * j12;
+  }
+  return o;
+}
+
+// cov2D entries (before the +0.3 low-pass) and V*a, V*b for the backward.
+__device__ __forceinline__ void cov2d_from(const ViewCov& vc, const float* c6, float& c00, float& c01,
+                                           float& c11, float* Va, float* Vb) {
+  const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    Va[i] = V[i][0] * vc.a[0] + V[i][1] * vc.a[1] + V[i][2] * vc.a[2];
+    Vb[i] = V[i][0] * vc.b[0] + V[i][1] * vc.b[1] + V[i][2] * vc.b[2];
+  }
+  c00 = vc.a[0] * Va[0] + vc.a[1] * Va[1] + vc.a[2] * Va[2];
+  c01 = vc.b[0] * Va[0] + vc.b[1] * Va[1] + vc.b[2] * Va[2];
+  c11 = vc.b[0] * Vb[0] + vc.b[1] * Vb[1] + vc.b[2] * Vb[2];
+}
+
+// Rstd[i][k]: rows as written in forward.cu:135-139 (glm column i), quaternion (r,x,y,z) NOT normalised.
+__device__ __forceinline__ void quat_rows(const float* q, float R[3][3]) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// auxiliary.h:41-44 is written with double literals: evaluate in double, round once.
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void get_rect(float px, float py, int rad, int gx, int gy, int& x0, int& y0, int& x1,
+                                         int& y1) {
+  // auxiliary.h:46-56: C-cast truncation toward zero, then clamp to the grid
+  x0 = min(gx, max(0, (int)((px - rad) / TILE)));
+  y0 = min(gy, max(0, (int)((py - rad) / TILE)));
+  x1 = min(gx, max(0, (int)((px + rad + TILE - 1) / TILE)));
+  y1 = min(gy, max(0, (int)((py + rad + TILE - 1) / TILE)));
+}
+
+// Number of tiles of the reference rect [x0,x1)x[y0,y1) that the alpha>=1/255 footprint bbox
+// (centre p, half extents h; h.x < 0 => none) reaches.  Tiles are TILE px wide, pixel centres are
+// integers, tile t covers pixels [t*TILE, t*TILE + TILE-1].
+__device__ __forceinline__ void tight_rect(float px, float py, float hx, float hy, int& x0, int& y0, int& x1,
+                                           int& y1) {
+  if (hx < 0.f) { x1 = x0; y1 = y0; return; }
+  // tile t is reached iff px+hx >= t*TILE and px-hx <= t*TILE+TILE-1
+  const int tx0 = (int)ceilf((px - hx - (TILE - 1)) / TILE), tx1 = (int)floorf((px + hx) / TILE) + 1;
+  const int ty0 = (int)ceilf((py - hy - (TILE - 1)) / TILE), ty1 = (int)floorf((py + hy) / TILE) + 1;
+  x0 = max(x0, tx0); x1 = max(x0, min(x1, tx1));
+  y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdPreArgs a, GeomView g, int32_t* __restrict__ radii) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.P) return;
+  int32_t radius_out = 0;
+  uint32_t touched = 0;
+  const float* __restrict__ vm = a.viewmatrix;
+  const float* __restrict__ pm = a.projmatrix;
+  const V3 p = ld3(a.means3D, idx);
+  const float view_z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+  if (view_z <= 0.2f) {  // auxiliary.h:154 near cull
+    if (a.prefiltered) atomicOr(&g.flags[0], 1u);
+  } else {
+    const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float ndc_x = (pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12]) * p_w;
+    const float ndc_y = (pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13]) * p_w;
+    float c6[6];
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) c6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+    } else {
+      float R[3][3];
+      quat_rows(a.rotations + 4 * (size_t)idx, R);
+      const V3 s = ld3(a.scales, idx);
+      const float sc[3] = {a.scale_modifier * s.x, a.scale_modifier * s.y, a.scale_modifier * s.z};
+      float m[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) m[i][k] = sc[k] * R[i][k];
+      c6[0] = m[0][0] * m[0][0] + m[0][1] * m[0][1] + m[0][2] * m[0][2];
+      c6[1] = m[0][0] * m[1][0] + m[0][1] * m[1][1] + m[0][2] * m[1][2];
+      c6[2] = m[0][0] * m[2][0] + m[0][1] * m[2][1] + m[0][2] * m[2][2];
+      c6[3] = m[1][0] * m[1][0] + m[1][1] * m[1][1] + m[1][2] * m[1][2];
+      c6[4] = m[1][0] * m[2][0] + m[1][1] * m[2][1] + m[1][2] * m[2][2];
+      c6[5] = m[2][0] * m[2][0] + m[2][1] * m[2][1] + m[2][2] * m[2][2];
+#pragma unroll
+      for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c6[i];
+    }
+    const ViewCov vc = view_cov(p, vm, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy);
+    float c00, c01, c11, Va[3], Vb[3];
+    cov2d_from(vc, c6, c00, c01, c11, Va, Vb);
+    c00 += 0.3f;
+    c11 += 0.3f;
+    const float det = c00 * c11 - c01 * c01;
+    if (det != 0.0f) {
+      const float det_inv = 1.f / det;
+      const float conx = c11 * det_inv, cony = -c01 * det_inv, conz = c00 * det_inv;
+      const float mid = 0.5f * (c00 + c11);
+      const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float my_radius = ceilf(3.f * sqrtf(fmaxf(mid + disc, mid - disc)));
+      const float px = ndc2pix(ndc_x, a.W), py = ndc2pix(ndc_y, a.H);
+      int x0, y0, x1, y1;
+      get_rect(px, py, (int)my_radius, a.tiles_x, a.tiles_y, x0, y0, x1, y1);
+      if ((x1 - x0) * (y1 - y0) != 0) {
+        const float opacity = a.opacities[idx];
+        // bbox of {alpha >= 1/255} = {q(d) <= 2 ln(255 o)}: half extents sqrt(tau * cov_xx), sqrt(tau * cov_yy)
+        // (cov = conic^-1 = the low-passed cov2D).  Inflated so it is conservative w.r.t. float rounding
+        // of the per-pixel test; the per-pixel test itself stays exact.
+        float hx = -1.f, hy = -1.f;
+        if (opacity * 255.0f >= 0.999f) {
+          const float tau = 2.0f * logf(fmaxf(opacity * 255.0f, 1.0f)) * 1.0001f + 1e-3f;
+          hx = fminf(sqrtf(tau * fmaxf(c00, 0.f)) * 1.0001f + 0.01f, 1e6f);
+          hy = fminf(sqrtf(tau * fmaxf(c11, 0.f)) * 1.0001f + 0.01f, 1e6f);
+          if (!(det > 0.f) || !(hx == hx) || !(hy == hy)) { hx = 1e6f; hy = 1e6f; }  // degenerate: never cull
+        }
+        if (a.tight_bins) tight_rect(px, py, hx, hy, x0, y0, x1, y1);
+        if (a.colors_precomp == nullptr) {
+          // forward.cu:21-72
+          const V3 cam = {a.campos[0], a.campos[1], a.campos[2]};
+          V3 dir = p - cam;
+          const float len = sqrtf(dot(dir, dir));
+          dir = {dir.x / len, dir.y / len, dir.z / len};
+          const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
+          auto SH = [&](int k) { return v3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+          V3 res = SH_C0 * SH(0);
+          if (a.D > 0) {
+            const float x = dir.x, y = dir.y, z = dir.z;
+            res = res - (SH_C1 * y) * SH(1) + (SH_C1 * z) * SH(2) - (SH_C1 * x) * SH(3);
+            if (a.D > 1) {
+              const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+              res = res + (SH_C2[0] * xy) * SH(4) + (SH_C2[1] * yz) * SH(5) +
+                    (SH_C2[2] * (2.0f * zz - xx - yy)) * SH(6) + (SH_C2[3] * xz) * SH(7) +
+                    (SH_C2[4] * (xx - yy)) * SH(8);
+              if (a.D > 2) {
+                res = res + (SH_C3[0] * y * (3.0f * xx - yy)) * SH(9) + (SH_C3[1] * xy * z) * SH(10) +
+                      (SH_C3[2] * y * (4.0f * zz - xx - yy)) * SH(11) +
+                      (SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * SH(12) +
+                      (SH_C3[4] * x * (4.0f * zz - xx - yy)) * SH(13) + (SH_C3[5] * z * (xx - yy)) * SH(14) +
+                      (SH_C3[6] * x * (xx - 3.0f * yy)) * SH(15);
+              }
+            }
+          }
+          res = res + v3(0.5f, 0.5f, 0.5f);
+          g.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+          g.rgb[3 * (size_t)idx + 0] = fmaxf(res.x, 0.f);
+          g.rgb[3 * (size_t)idx + 1] = fmaxf(res.y, 0.f);
+          g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
+        }
+        g.depths[idx] = view_z;
+        g.means2D[idx] = make_float2(px, py);
+        g.conic_opacity[idx] = make_float4(conx, cony, conz, opacity);
+        g.cullext[idx] = make_float2(hx, hy);
+        radius_out = (int32_t)my_radius;
+        touched = (uint32_t)((y1 - y0) * (x1 - x0));
+      }
+    }
+  }
+  radii[idx] = radius_out;
+  g.tiles_touched[idx] = touched;
+}
+
+hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
+  if (a.P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, g, radii);
+  return hipGetLastError();
+}
+
+// ---- frustum marking (rasterizer_impl.cu:54-66) ---------------------------------------------------
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ vm,
+                                    uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+  const V3 p = ld3(means, idx);
+  const float z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+  present[idx] = (z <= 0.2f) ? 0 : 1;
+}
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
+                               hipStream_t s) {
+  (void)proj;  // the projected point is computed but unused by the reference test (auxiliary.h:148-154)
+  if (P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+  return hipGetLastError();
+}
+
+// ---- fused backward preprocess: K9 (conic -> cov3D, mean) + K10 (projection, SH, scale/rot) --------
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.P) return;
+  const size_t i = (size_t)idx;
+  const bool vis = a.radii[idx] > 0;
+  float acc[8];
+  {
+    const float4 u = reinterpret_cast<const float4*>(a.acc8)[2 * i];
+    const float4 v = reinterpret_cast<const float4*>(a.acc8)[2 * i + 1];
+    acc[0] = u.x; acc[1] = u.y; acc[2] = u.z; acc[3] = u.w; acc[4] = v.x; acc[5] = v.y;
+  }
+  // render-backward sums: a non-visible Gaussian is in no tile list, so they are already zero.
+  a.dL_dmeans2D[3 * i + 0] = acc[0];
+  a.dL_dmeans2D[3 * i + 1] = acc[1];
+  a.dL_dmeans2D[3 * i + 2] = 0.f;
+  a.dL_dopacity[i] = acc[5];
+  if (a.dL_dconic) {
+    a.dL_dconic[4 * i + 0] = acc[2]; a.dL_dconic[4 * i + 1] = acc[3];
+    a.dL_dconic[4 * i + 2] = 0.f;    a.dL_dconic[4 * i + 3] = acc[4];
+  }
+  float g_mean[3] = {0, 0, 0}, g_cov[6] = {0, 0, 0, 0, 0, 0}, g_scale[3] = {0, 0, 0}, g_rot[4] = {0, 0, 0, 0};
+  const int n_sh = a.M;
+  if (!vis) {
+    if (a.dL_dsh)
+      for (int k = 0; k < 3 * n_sh; k++) a.dL_dsh[i * 3 * n_sh + k] = 0.f;
+  } else {
+    const float* __restrict__ vm = a.viewmatrix;
+    const float* __restrict__ proj = a.projmatrix;
+    const V3 m = ld3(a.means3D, idx);
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+    // ---- K9: backward.cu:144-274 ----
+    const ViewCov vc = view_cov(m, vm, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy);
+    float c00, c01, c11, Va[3], Vb[3];
+    cov2d_from(vc, c6, c00, c01, c11, Va, Vb);
+    const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+    const float x_grad_mul = (vc.txtz < -limx || vc.txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (vc.tytz < -limy || vc.tytz > limy) ? 0.f : 1.f;
+    const float ca = c00 + 0.3f, cb = c01, cc = c11 + 0.3f;
+    const float dcx = acc[2], dcy = acc[3], dcz = acc[4];
+    const float denom = ca * cc - cb * cb;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    if (denom2inv != 0) {
+      dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+      dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+      dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+      const float* A = vc.a; const float* B = vc.b;
+      g_cov[0] = A[0] * A[0] * dL_da + A[0] * B[0] * dL_db + B[0] * B[0] * dL_dc;
+      g_cov[3] = A[1] * A[1] * dL_da + A[1] * B[1] * dL_db + B[1] * B[1] * dL_dc;
+      g_cov[5] = A[2] * A[2] * dL_da + A[2] * B[2] * dL_db + B[2] * B[2] * dL_dc;
+      g_cov[1] = 2 * A[0] * A[1] * dL_da + (A[0] * B[1] + A[1] * B[0]) * dL_db + 2 * B[0] * B[1] * dL_dc;
+      g_cov[2] = 2 * A[0] * A[2] * dL_da + (A[0] * B[2] + A[2] * B[0]) * dL_db + 2 * B[0] * B[2] * dL_dc;
+      g_cov[4] = 2 * A[2] * A[1] * dL_da + (A[1] * B[2] + A[2] * B[1]) * dL_db + 2 * B[1] * B[2] * dL_dc;
+    }
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      dT0[j] = 2 * Va[j] * dL_da + Vb[j] * dL_db;
+      dT1[j] = 2 * Vb[j] * dL_dc + Va[j] * dL_db;
+    }
+    const float dJ00 = vm[0] * dT0[0] + vm[4] * dT0[1] + vm[8] * dT0[2];
+    const float dJ02 = vm[2] * dT0[0] + vm[6] * dT0[1] + vm[10] * dT0[2];
+    const float dJ11 = vm[1] * dT1[0] + vm[5] * dT1[1] + vm[9] * dT1[2];
+    const float dJ12 = vm[2] * dT1[0] + vm[6] * dT1[1] + vm[10] * dT1[2];
+    const float tz = 1.f / vc.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float hx = a.focal_x, hy = a.focal_y;
+    const float dtx = x_grad_mul * -hx * tz2 * dJ02;
+    const float dty = y_grad_mul * -hy * tz2 * dJ12;
+    const float dtz = -hx * tz2 * dJ00 - hy * tz2 * dJ11 + (2 * hx * vc.tx) * tz3 * dJ02 + (2 * hy * vc.ty) * tz3 * dJ12;
+    g_mean[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;   // transformVec4x3Transpose
+    g_mean[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+    g_mean[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+    // ---- K10: projection path, backward.cu:369-387 ----
+    const float hw = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
+    const float m_w = 1.0f / (hw + 0.0000001f);
+    const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+    const float gx = acc[0], gy = acc[1];
+    g_mean[0] += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
+    g_mean[1] += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
+    g_mean[2] += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
+    // ---- SH backward, backward.cu:20-139 ----
+    if (a.shs) {
+      const V3 cam = {a.campos[0], a.campos[1], a.campos[2]};
+      const V3 dir_orig = m - cam;
+      const float len = sqrtf(dot(dir_orig, dir_orig));
+      const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
+      const float* __restrict__ sh = a.shs + i * n_sh * 3;
+      auto SH = [&](int k) { return v3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+      const uint8_t cl = a.clamped[idx];
+      V3 dRGB = ld3(a.dL_dcolor, idx);
+      dRGB.x *= (cl & 1) ? 0.f : 1.f;
+      dRGB.y *= (cl & 2) ? 0.f : 1.f;
+      dRGB.z *= (cl & 4) ? 0.f : 1.f;
+      float* __restrict__ o = a.dL_dsh + i * n_sh * 3;
+      auto ST = [&](int k, float w) { o[3 * k] = w * dRGB.x; o[3 * k + 1] = w * dRGB.y; o[3 * k + 2] = w * dRGB.z; };
+      V3 dx = {0, 0, 0}, dy = {0, 0, 0}, dz = {0, 0, 0};
+      const float x = dir.x, y = dir.y, z = dir.z;
+      ST(0, SH_C0);
+      int written = 1;
+      if (a.D > 0) {
+        ST(1, -SH_C1 * y); ST(2, SH_C1 * z); ST(3, -SH_C1 * x);
+        written = 4;
+        dx = (-SH_C1) * SH(3); dy = (-SH_C1) * SH(1); dz = SH_C1 * SH(2);
+        if (a.D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          ST(4, SH_C2[0] * xy); ST(5, SH_C2[1] * yz); ST(6, SH_C2[2] * (2.f * zz - xx - yy));
+          ST(7, SH_C2[3] * xz); ST(8, SH_C2[4] * (xx - yy));
+          written = 9;
+          dx = dx + (SH_C2[0] * y) * SH(4) + (SH_C2[2] * 2.f * -x) * SH(6) + (SH_C2[3] * z) * SH(7) + (SH_C2[4] * 2.f * x) * SH(8);
+          dy = dy + (SH_C2[0] * x) * SH(4) + (SH_C2[1] * z) * SH(5) + (SH_C2[2] * 2.f * -y) * SH(6) + (SH_C2[4] * 2.f * -y) * SH(8);
+          dz = dz + (SH_C2[1] * y) * SH(5) + (SH_C2[2] * 2.f * 2.f * z) * SH(6) + (SH_C2[3] * x) * SH(7);
+          if (a.D > 2) {
+            ST(9, SH_C3[0] * y * (3.f * xx - yy)); ST(10, SH_C3[1] * xy * z);
+            ST(11, SH_C3[2] * y * (4.f * zz - xx - yy)); ST(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+            ST(13, SH_C3[4] * x * (4.f * zz - xx - yy)); ST(14, SH_C3[5] * z * (xx - yy));
+            ST(15, SH_C3[6] * x * (xx - 3.f * yy));
+            written = 16;
+            dx = dx + (SH_C3[0] * 3.f * 2.f * xy) * SH(9) + (SH_C3[1] * yz) * SH(10) + (SH_C3[2] * -2.f * xy) * SH(11) +
+                 (SH_C3[3] * -3.f * 2.f * xz) * SH(12) + (SH_C3[4] * (-3.f * xx + 4.f * zz - yy)) * SH(13) +
+                 (SH_C3[5] * 2.f * xz) * SH(14) + (SH_C3[6] * 3.f * (xx - yy)) * SH(15);
+            dy = dy + (SH_C3[0] * 3.f * (xx - yy)) * SH(9) + (SH_C3[1] * xz) * SH(10) +
+                 (SH_C3[2] * (-3.f * yy + 4.f * zz - xx)) * SH(11) + (SH_C3[3] * -3.f * 2.f * yz) * SH(12) +
+                 (SH_C3[4] * -2.f * xy) * SH(13) + (SH_C3[5] * -2.f * yz) * SH(14) + (SH_C3[6] * -3.f * 2.f * xy) * SH(15);
+            dz = dz + (SH_C3[1] * xy) * SH(10) + (SH_C3[2] * 4.f * 2.f * yz) * SH(11) +
+                 (SH_C3[3] * 3.f * (2.f * zz - xx - yy)) * SH(12) + (SH_C3[4] * 4.f * 2.f * xz) * SH(13) +
+                 (SH_C3[5] * (xx - yy)) * SH(14);
+          }
+        }
+      }
+      for (int k = written; k < n_sh; k++) ST(k, 0.f);  // coefficients above the active degree keep zero
+      const V3 dL_ddir = {dot(dx, dRGB), dot(dy, dRGB), dot(dz, dRGB)};
+      // dnormvdv, auxiliary.h:107-117
+      const V3 v = dir_orig;
+      const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      g_mean[0] += ((+sum2 - v.x * v.x) * dL_ddir.x - v.y * v.x * dL_ddir.y - v.z * v.x * dL_ddir.z) * invsum32;
+      g_mean[1] += (-v.x * v.y * dL_ddir.x + (sum2 - v.y * v.y) * dL_ddir.y - v.z * v.y * dL_ddir.z) * invsum32;
+      g_mean[2] += (-v.x * v.z * dL_ddir.x - v.y * v.z * dL_ddir.y + (sum2 - v.z * v.z) * dL_ddir.z) * invsum32;
+    }
+    // ---- cov3D backward, backward.cu:278-341 ----
+    if (a.scales) {
+      float R[3][3];
+      const float* q = a.rotations + 4 * i;
+      quat_rows(q, R);
+      const V3 s0 = ld3(a.scales, idx);
+      const float sc[3] = {a.scale_modifier * s0.x, a.scale_modifier * s0.y, a.scale_modifier * s0.z};
+      const float dS[3][3] = {{g_cov[0], 0.5f * g_cov[1], 0.5f * g_cov[2]},
+                              {0.5f * g_cov[1], g_cov[3], 0.5f * g_cov[4]},
+                              {0.5f * g_cov[2], 0.5f * g_cov[4], g_cov[5]}};
+      // Q[c][r] = dL_dMt[c][r] = 2 * s_c * sum_k R[k][c] * dS[r][k]
+      float Q[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          Q[c][r] = 2.0f * (sc[c] * R[0][c] * dS[r][0] + sc[c] * R[1][c] * dS[r][1] + sc[c] * R[2][c] * dS[r][2]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) g_scale[c] = R[0][c] * Q[c][0] + R[1][c] * Q[c][1] + R[2][c] * Q[c][2];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) Q[c][r] *= sc[c];
+      const float r = q[0], x = q[1], y = q[2], z = q[3];
+      g_rot[0] = 2 * z * (Q[0][1] - Q[1][0]) + 2 * y * (Q[2][0] - Q[0][2]) + 2 * x * (Q[1][2] - Q[2][1]);
+      g_rot[1] = 2 * y * (Q[1][0] + Q[0][1]) + 2 * z * (Q[2][0] + Q[0][2]) + 2 * r * (Q[1][2] - Q[2][1]) - 4 * x * (Q[2][2] + Q[1][1]);
+      g_rot[2] = 2 * x * (Q[1][0] + Q[0][1]) + 2 * r * (Q[2][0] - Q[0][2]) + 2 * z * (Q[1][2] + Q[2][1]) - 4 * y * (Q[2][2] + Q[0][0]);
+      g_rot[3] = 2 * r * (Q[0][1] - Q[1][0]) + 2 * x * (Q[2][0] + Q[0][2]) + 2 * y * (Q[1][2] + Q[2][1]) - 4 * z * (Q[1][1] + Q[0][0]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) a.dL_dmeans3D[3 * i + k] = g_mean[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = g_cov[k];
+  if (a.dL_dscales) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.dL_dscales[3 * i + k] = g_scale[k];
+  }
+  if (a.dL_drot) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = g_rot[k];
+  }
+}
+
+hipError_t launch_preprocess_bwd(const BwdPreArgs& a, hipStream_t s) {
+  if (a.P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace mgs

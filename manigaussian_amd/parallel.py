@@ -1,0 +1,65 @@
+"""Multi-GPU data path: independent (view, timestep) renders sharded over ranks, one all-reduce of the
+per-Gaussian gradients.
+
+One process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo on CPU.  The path has no
+exchange step inside forward or backward -- every render reads the replicated Gaussian set and adds its
+gradient contribution -- so the only collective is ONE sum all-reduce per step over a single flat fp32
+bucket that all gradient tensors alias (no per-tensor launches, no copy into a staging buffer).
+
+The reference reaches multi-GPU only through Lightning Fabric DDP over replay samples
+(train.py:94-95, agents/manigaussian_bc/qattention_manigaussian_bc_agent.py:155,163) and renders strictly
+one view per call (agents/manigaussian_bc/neural_rendering.py:386).
+"""
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin: rank g takes items {i : i mod world == g}."""
+    return list(range(rank, n_items, world))
+
+
+class GradBucket:
+    """One flat fp32 buffer; each parameter's .grad is a view into it."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        self.names = list(params)
+        self.params = params
+        dev = next(iter(params.values())).device
+        sizes = [params[n].numel() for n in self.names]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.views = {}
+        off = 0
+        for n, sz in zip(self.names, sizes):
+            self.views[n] = self.flat[off:off + sz].view_as(params[n])
+            off += sz
+
+    def attach(self):
+        """Zero the bucket and (re)point every .grad at its view; autograd then accumulates in place."""
+        self.flat.zero_()
+        for n in self.names:
+            self.params[n].grad = self.views[n]
+
+    def all_reduce(self, group=None, async_op: bool = False):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
+
+
+def render_sharded(params: Dict[str, torch.Tensor], items: Sequence, render_item: Callable, bucket: GradBucket,
+                   rank: int = 0, world: int = 1, group=None):
+    """Render this rank's share of `items` (views / (timestep, view) pairs), back-propagate each one into
+    the shared bucket, then all-reduce the bucket once.
+
+    render_item(params, item) -> scalar loss tensor whose backward reaches `params`.
+    Returns (local losses, work handle or None)."""
+    bucket.attach()
+    losses = []
+    for i in shard_indices(len(items), rank, world):
+        loss = render_item(params, items[i])
+        loss.backward()
+        losses.append(loss.detach())
+    handle = bucket.all_reduce(group)
+    return losses, handle

@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests: run the same seeded scene through Oracle B (CPU) and the HIP path."""
+import types
+
+import torch
+
+from manigaussian_amd import synthetic as syn
+
+
+def scene_case(P, F=3, M=4, W=128, H=128, neg=True, colors_precomp=False, bg=(0.1, 0.2, 0.3), sh_degree=1,
+               include_feature=True, seed=0, cam_index=1, unnormalized_rot=False, cov3d=False):
+    sc = syn.make_scene(P, F=F if include_feature else 0, M=M, seed=seed, colors_precomp=colors_precomp,
+                        unnormalized_rot=unnormalized_rot)
+    if cov3d:  # precomputed covariance instead of scale/rotation
+        R = sc.pop("rotations")
+        s = sc.pop("scales")
+        r, x, y, z = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+        Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                          2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                          2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        RS = Rm * s[:, None, :]
+        Sg = RS @ RS.transpose(1, 2)
+        sc["cov3D_precomp"] = torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2],
+                                           Sg[:, 2, 2]], 1).contiguous()
+    cam = syn.circle_cameras(4, W, H, negative_focal=neg)[cam_index]
+    kw = syn.camera_settings_kwargs(cam, sh_degree, include_feature, bg=bg)
+    dC, dF = syn.make_cotangents(W, H, F if include_feature else 0)
+    return sc, cam, kw, dC, dF
+
+
+def run_oracle_b(sc, kw, dC, dF):
+    from oracle import oracle_b
+    st = types.SimpleNamespace(**kw)
+    color, feat, radii, state = oracle_b.forward(
+        sc["means3D"], sc["opacities"], st, shs=sc.get("shs"), colors_precomp=sc.get("colors_precomp"),
+        language_feature=sc.get("language_feature"), scales=sc.get("scales"), rotations=sc.get("rotations"),
+        cov3D_precomp=sc.get("cov3D_precomp"))
+    grads = oracle_b.backward(state, dC, dF)
+    return color, feat, radii, grads, state
+
+
+def run_hip(sc, cam, dC, dF, sh_degree, include_feature, bg, device="cuda:0", debug=False):
+    from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device(device)
+    kw = syn.camera_settings_kwargs(cam, sh_degree, include_feature, bg=bg, device=dev, debug=debug)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    P = sc["means3D"].shape[0]
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**kw))
+    color, feat, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                              shs=leaves.get("shs"), colors_precomp=leaves.get("colors_precomp"),
+                              language_feature_precomp=leaves.get("language_feature"), scales=leaves.get("scales"),
+                              rotations=leaves.get("rotations"), cov3D_precomp=leaves.get("cov3D_precomp"))
+    loss = (color * dC.to(dev)).sum()
+    if include_feature:
+        loss = loss + (feat * dF.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: v.grad.detach().cpu() for k, v in leaves.items() if v.grad is not None}
+    grads["means2D"] = means2D.grad.detach().cpu()
+    return color.detach().cpu(), feat.detach().cpu(), radii.cpu(), grads
+
+
+# name in the HIP leaves -> name in the oracle's gradient dict
+GRAD_KEYS = {"means3D": "means3D", "means2D": "means2D", "opacities": "opacities", "scales": "scales",
+             "rotations": "rotations", "shs": "sh", "colors_precomp": "colors_precomp",
+             "language_feature": "language_feature", "cov3D_precomp": "cov3D"}
+
+
+def grad_errors(g_hip, g_ref):
+    """{name: (max abs err, max |ref|)}"""
+    out = {}
+    for k, v in g_hip.items():
+        r = g_ref[GRAD_KEYS[k]].reshape(v.shape)
+        out[k] = ((v - r).abs().max().item() if v.numel() else 0.0, r.abs().max().item() if r.numel() else 0.0)
+    return out
