@@ -1,0 +1,300 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the public API and the C ABI,
+against Oracle B on the same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's
+full sizes -- through size-independent properties.
+
+Tolerances (BASELINE.json north_star): 1e-4 absolute on rendered RGB / feature maps; gradients within 1e-3 of
+the tensor's largest gradient magnitude (the per-Gaussian sums are float atomics in arbitrary order, in the
+reference as well: RAST/cuda_rasterizer/backward.cu:541-590)."""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+from manigaussian_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+GRAD_TOL = 1e-3
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    L = _lib.lib()
+    assert os.path.samefile(L._name, os.path.join(os.path.dirname(_lib.__file__), "libmgsplat.so"))
+    yield
+
+
+def _check(case, tight_bins=None):
+    if tight_bins is not None:
+        _lib.set_option("tight_bins", tight_bins)
+    sc, cam, kw, dC, dF = util.scene_case(**case)
+    inc = case.get("include_feature", True)
+    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case.get("bg", (0.1, 0.2, 0.3)))
+    assert torch.equal(rh, rr), "radii differ"
+    assert (ch - cr).abs().max().item() <= IMG_TOL
+    if inc:
+        assert fh.shape == fr.shape
+        assert (fh - fr).abs().max().item() <= IMG_TOL
+    else:
+        assert fh.shape == (1,)
+    for k, (err, mag) in util.grad_errors(gh, gr).items():
+        assert err <= GRAD_TOL * mag + 1e-7, f"grad {k}: err {err:.3e} vs max {mag:.3e}"
+    return st
+
+
+def test_wave64_primitives_selftest():
+    assert _lib.lib().mgs_selftest(None) == 0, _lib.last_error()
+
+
+CASES = {
+    "manigaussian_shape_16k_f3_negfocal": dict(P=16384, F=3),
+    "f32_posfocal": dict(P=6000, F=32, neg=False),
+    "precomp_rgb_only": dict(P=5000, F=3, colors_precomp=True, include_feature=False),
+    "sh3_unnormalised_quat": dict(P=3000, F=3, M=16, sh_degree=3, unnormalized_rot=True),
+    "sh2_f4_black_bg": dict(P=3000, F=4, M=9, sh_degree=2, bg=(0.0, 0.0, 0.0)),
+    "cov3d_precomp_odd_size": dict(P=3000, F=3, cov3d=True, W=72, H=40),
+    "padded_feature_width_f5": dict(P=2000, F=5),
+    "f8": dict(P=2000, F=8), "f16": dict(P=2000, F=16), "f64": dict(P=1500, F=64),
+    "image_256": dict(P=8000, F=32, W=256, H=256),
+    "tiny_image_8x8": dict(P=500, F=3, W=8, H=8),
+    "other_view": dict(P=4000, F=3, cam_index=3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("tight", [0, 1])
+def test_parity_with_oracle(name, tight):
+    _check(CASES[name], tight_bins=tight)
+
+
+def test_reference_reduction_variant_agrees():
+    """bwd_reduce=0 (plain shuffles) and 1 (permlane-swap butterfly) are two implementations of one sum."""
+    for red in (0, 1):
+        _lib.set_option("bwd_reduce", red)
+        _check(dict(P=3000, F=32))
+    _lib.set_option("bwd_reduce", 1)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(path):
+    z = np.load(path)
+    case = eval(bytes(z["case"]).decode())
+    sc = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    cam = {k[4:]: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files if k.startswith("cam_")}
+    inc = case.get("include_feature", True)
+    dC = torch.from_numpy(z["d_color"])
+    dF = torch.from_numpy(z["d_feat"]) if "d_feat" in z.files else None
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case.get("bg", (0.1, 0.2, 0.3)))
+    assert np.array_equal(rh.numpy(), z["radii"])
+    assert np.abs(ch.numpy() - z["out_color"]).max() <= IMG_TOL
+    if inc:
+        assert np.abs(fh.numpy() - z["out_feat"]).max() <= IMG_TOL
+    for k, v in gh.items():
+        ref = z["grad_" + util.GRAD_KEYS[k]].reshape(v.shape)
+        if ref.size:
+            assert np.abs(v.numpy() - ref).max() <= GRAD_TOL * np.abs(ref).max() + 1e-7, k
+
+
+def test_edge_cases_empty_and_all_culled():
+    dev = torch.device("cuda:0")
+    sc, cam, kw, dC, dF = util.scene_case(P=50, F=3, W=32, H=32)
+    st = GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, bg=(0.1, 0.2, 0.3), device=dev))
+    r = GaussianRasterizer(st)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    # P == 0 (rasterize_points.cu:92): zero images, empty radii
+    c, f, rad = r(z(0, 3), z(0, 3), z(0, 1), shs=z(0, 4, 3), language_feature_precomp=z(0, 3), scales=z(0, 3),
+                  rotations=z(0, 4))
+    assert c.shape == (3, 32, 32) and c.abs().max() == 0 and rad.numel() == 0
+    # everything behind the camera: R == 0, image == background, all gradients zero
+    sc["means3D"] = sc["means3D"] * 0 + cam["camera_center"] - 5.0
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, True, (0.1, 0.2, 0.3))
+    assert (rh == 0).all() and fh.abs().max() == 0
+    assert torch.allclose(ch, torch.tensor([0.1, 0.2, 0.3]).reshape(3, 1, 1).expand_as(ch))
+    assert all(v.abs().max() == 0 for v in gh.values())
+    assert not r.markVisible(sc["means3D"].to(dev)).any()
+
+
+def test_mark_visible_matches_oracle():
+    from oracle import oracle_b
+    sc, cam, kw, _, _ = util.scene_case(P=5000, F=3)
+    pts = sc["means3D"] * 3.0 - 1.0
+    dev = torch.device("cuda:0")
+    r = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    got = r.markVisible(pts.to(dev)).cpu()
+    assert got.dtype == torch.bool and torch.equal(got, oracle_b.mark_visible(pts, kw["viewmatrix"], kw["projmatrix"]))
+
+
+def test_debug_mode_and_prefiltered_trap():
+    sc, cam, kw, dC, dF = util.scene_case(P=800, F=3, W=32, H=32)
+    util.run_hip(sc, cam, dC, dF, 1, True, (0, 0, 0), debug=True)  # stage-by-stage sync path
+    dev = torch.device("cuda:0")
+    k = syn.camera_settings_kwargs(cam, 1, True, device=dev)
+    k["prefiltered"] = True
+    sc["means3D"][0] = cam["camera_center"] - 5.0  # one culled point although prefiltered is claimed
+    d = {n: v.to(dev) for n, v in sc.items()}
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        GaussianRasterizer(GaussianRasterizationSettings(**k))(
+            d["means3D"], torch.zeros_like(d["means3D"]), d["opacities"], shs=d["shs"],
+            language_feature_precomp=d["language_feature"], scales=d["scales"], rotations=d["rotations"])
+
+
+def test_render_wrapper_matches_direct_call():
+    """manigaussian_amd.gaussian_renderer.render == MG/gaussian_renderer/__init__.py:render semantics."""
+    from manigaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    sc, cam, kw, dC, dF = util.scene_case(P=3000, F=3)
+    raw_feat = torch.randn(3000, 3, generator=torch.Generator().manual_seed(5))
+    data = {"novel_view": {"FovX": [cam["FovX"]], "FovY": [cam["FovY"]], "width": [128], "height": [128],
+                           "world_view_transform": cam["world_view_transform"][None].to(dev),
+                           "full_proj_transform": cam["full_proj_transform"][None].to(dev),
+                           "camera_center": cam["camera_center"][None].to(dev)}}
+    d = {k: v.to(dev) for k, v in sc.items()}
+    out = render(data, 0, d["means3D"], d["rotations"], d["scales"], d["opacities"], [0.1, 0.2, 0.3],
+                 features_color=d["shs"], features_language=raw_feat.to(dev))
+    sc["language_feature"] = raw_feat / (raw_feat.norm(dim=-1, keepdim=True) + 1e-12)
+    cr, fr, rr, _, _ = util.run_oracle_b(sc, kw, dC, dF)
+    assert (out["render"].cpu() - cr).abs().max() <= IMG_TOL and (out["render_embed"].cpu() - fr).abs().max() <= IMG_TOL
+    assert torch.equal(out["radii"].cpu(), rr) and out["viewspace_points"].shape == (3000, 3)
+    # no language features: zeros [N,3] placeholder, include_feature False -> [1] output
+    out = render(data, 0, d["means3D"], d["rotations"], d["scales"], d["opacities"], [0.1, 0.2, 0.3],
+                 pts_rgb=torch.rand(3000, 3, device=dev))
+    assert out["render_embed"].shape == (1,)
+
+
+# ---- full BASELINE sizes: properties that need no oracle run -------------------------------------------
+
+def _full(P=100000, F=32, W=128, H=128, cam_index=1, bg=(0.0, 0.0, 0.0)):
+    dev = torch.device("cuda:0")
+    sc = syn.make_scene(P, F=F, M=4, seed=0)
+    cam = syn.circle_cameras(4, W, H, negative_focal=True)[cam_index]
+    st = GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, bg=bg, device=dev))
+    return {k: v.to(dev) for k, v in sc.items()}, GaussianRasterizer(st), cam
+
+
+def _fwd_bwd(d, rast, dC, dF):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in d.items()}
+    c, f, r = rast(leaves["means3D"], torch.zeros_like(leaves["means3D"]), leaves["opacities"], shs=leaves["shs"],
+                   language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                   rotations=leaves["rotations"])
+    torch.autograd.backward([c, f], [dC, dF])
+    return c.detach(), f.detach(), r, {k: v.grad for k, v in leaves.items()}
+
+
+@pytest.mark.parametrize("P,W", [(100000, 128), (500000, 256)], ids=["C3_100k_128", "C5_500k_256"])
+def test_full_size_properties(P, W):
+    """(1) backward is linear in the cotangent; (2) forward is bit-deterministic; (3) a Gaussian permutation
+    permutes radii and gradients and leaves the image unchanged up to equal-depth ties; (4) 0 <= image."""
+    d, rast, cam = _full(P=P, W=W, H=W)
+    dev = d["means3D"].device
+    g = torch.Generator().manual_seed(7)
+    dC1, dF1 = torch.randn(3, W, W, generator=g).to(dev), torch.randn(32, W, W, generator=g).to(dev)
+    dC2, dF2 = torch.randn(3, W, W, generator=g).to(dev), torch.randn(32, W, W, generator=g).to(dev)
+    c1, f1, r1, g1 = _fwd_bwd(d, rast, dC1, dF1)
+    c2, f2, r2, g2 = _fwd_bwd(d, rast, dC2, dF2)
+    assert torch.equal(c1, c2) and torch.equal(f1, f2) and torch.equal(r1, r2)
+    assert c1.min() >= 0 and torch.isfinite(c1).all() and torch.isfinite(f1).all()
+    _, _, _, g12 = _fwd_bwd(d, rast, 2.0 * dC1 - 3.0 * dC2, 2.0 * dF1 - 3.0 * dF2)
+    for k in g1:
+        ref = 2.0 * g1[k] - 3.0 * g2[k]
+        scale = max(g1[k].abs().max().item(), g2[k].abs().max().item())
+        assert (g12[k] - ref).abs().max().item() <= 2e-4 * scale, k
+        assert torch.isfinite(g12[k]).all()
+    perm = torch.randperm(P, generator=g).to(dev)
+    dp = {k: v[perm].contiguous() for k, v in d.items()}
+    cp, fp, rp, gp = _fwd_bwd(dp, rast, dC1, dF1)
+    assert torch.equal(rp, r1[perm])
+    assert (cp - c1).abs().max().item() <= IMG_TOL and (fp - f1).abs().max().item() <= IMG_TOL
+    for k in g1:
+        assert (gp[k] - g1[k][perm]).abs().max().item() <= GRAD_TOL * g1[k].abs().max().item(), k
+
+
+def test_tight_bins_is_result_preserving_at_full_size():
+    d, rast, cam = _full()
+    dev = d["means3D"].device
+    g = torch.Generator().manual_seed(9)
+    dC, dF = torch.randn(3, 128, 128, generator=g).to(dev), torch.randn(32, 128, 128, generator=g).to(dev)
+    _lib.set_option("tight_bins", 0)
+    c0, f0, r0, g0 = _fwd_bwd(d, rast, dC, dF)
+    _lib.set_option("tight_bins", 1)
+    c1, f1, r1, g1 = _fwd_bwd(d, rast, dC, dF)
+    assert torch.equal(c0, c1) and torch.equal(f0, f1) and torch.equal(r0, r1)  # same pairs blended, same order
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * g0[k].abs().max().item() + 1e-9, k
+
+
+def test_sharded_views_on_gpu_equal_sum_of_views():
+    """render_sharded() with the HIP rasterizer, world=1: bucket == sum over views of per-view gradients."""
+    from manigaussian_amd.parallel import GradBucket, render_sharded
+    dev = torch.device("cuda:0")
+    P, W, F, V = 20000, 128, 32, 4
+    sc = syn.make_scene(P, F=F, M=4, seed=0)
+    cams = syn.circle_cameras(V, W, W, negative_focal=True)
+    items = []
+    for v, cam in enumerate(cams):
+        dC, dF = syn.make_cotangents(W, W, F, seed=20 + v)
+        items.append((GaussianRasterizer(GaussianRasterizationSettings(
+            **syn.camera_settings_kwargs(cam, 1, True, device=dev))), dC.to(dev), dF.to(dev)))
+
+    def render_item(params, item):
+        rast, dC, dF = item
+        c, f, _ = rast(params["means3D"], torch.zeros_like(params["means3D"]), params["opacities"], shs=params["shs"],
+                       language_feature_precomp=params["language_feature"], scales=params["scales"],
+                       rotations=params["rotations"])
+        return (c * dC).sum() + (f * dF).sum()
+
+    params = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    bucket = GradBucket(params)
+    render_sharded(params, items, render_item, bucket)
+    total = {k: p.grad.clone() for k, p in params.items()}
+    acc = {k: torch.zeros_like(v) for k, v in total.items()}
+    for it in items:
+        gs = torch.autograd.grad(render_item(params, it), list(params.values()))
+        for k, g_ in zip(params, gs):
+            acc[k] += g_
+    for k in total:
+        assert (total[k] - acc[k]).abs().max().item() <= 1e-4 * acc[k].abs().max().item() + 1e-9, k
+
+
+# ---- deformation-field kernels ---------------------------------------------------------------------
+
+def test_deform_apply_and_assembly_match_torch():
+    from manigaussian_amd.deform import DeformationField, assemble_deform_input, deform_apply
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    N = 16384
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    lat, z = rn(N, 128).requires_grad_(True), rn(N, 39).requires_grad_(True)
+    xyz, sh, rot, scale, op, feat, act = rn(N, 3), rn(N, 4, 3), rn(N, 4), rn(N, 3), rn(N, 1), rn(N, 3), rn(1, 8)
+    for use_feat in (False, True):
+        out = assemble_deform_input(lat, z, xyz, sh, rot, scale, op, feat if use_feat else None, act)
+        parts = [lat, xyz, sh[:, 0], sh[:, 1:].reshape(N, 9), rot, scale, op] + ([feat] if use_feat else []) + \
+                [z, act.repeat(N, 1)]                      # models_embed.py:258-287
+        ref = torch.cat(parts, -1)
+        assert out.shape == ref.shape == (N, 128 + (73 if use_feat else 70)) and torch.equal(out, ref)
+        w = rn(*out.shape)
+        g1 = torch.autograd.grad((out * w).sum(), [lat, z])
+        g2 = torch.autograd.grad((ref * w).sum(), [lat, z])
+        assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    delta = rn(N, 7).requires_grad_(True)
+    nx, nr = deform_apply(delta, xyz, rot)
+    rx, rr = xyz + delta[:, :3], torch.nn.functional.normalize(rot + delta[:, 3:], dim=-1)  # models_embed.py:297-299
+    assert torch.allclose(nx, rx, atol=1e-6) and torch.allclose(nr, rr, atol=1e-6)
+    wx, wr = rn(N, 3), rn(N, 4)
+    ga = torch.autograd.grad((nx * wx).sum() + (nr * wr).sum(), delta)[0]
+    gb = torch.autograd.grad((rx * wx).sum() + (rr * wr).sum(), delta)[0]
+    assert torch.allclose(ga, gb, atol=1e-5, rtol=1e-4)
+    field = DeformationField().to(dev)
+    nxt = field(lat, z, xyz, sh, rot, scale, op, action=act)
+    assert nxt["xyz"].shape == (N, 3) and nxt["rot"].shape == (N, 4)
+    assert torch.allclose(nxt["rot"].norm(dim=-1), torch.ones(N, device=dev), atol=1e-5)
+    (nxt["xyz"].sum() + nxt["rot"].sum()).backward()
+    assert lat.grad is not None and torch.isfinite(lat.grad).all()
