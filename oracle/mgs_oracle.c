@@ -456,6 +456,49 @@ static void render_fwd(OrcState* s, float* out_color, float* out_feat) {
   }
 }
 
+/* Test aid, not part of the reference: marks pixels whose forward walk passes within rel_eps of one of
+ * the reference's three hard decisions (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4; forward.cu:345-360).
+ * At such a pixel two correct implementations that differ by one ulp in exp() can legitimately blend a
+ * different set of Gaussians (a step of up to ~alpha*T*c = 4e-3), so parity tests compare them with a
+ * looser bound and require them to be rare. */
+void orc_fragile_mask(const OrcState* s, float rel_eps, uint8_t* mask, uint8_t* gmask /*[P] or NULL*/) {
+  const int W = s->W, H = s->H;
+  const int T = s->gx * s->gy;
+  memset(mask, 0, (size_t)W * H);
+  if (gmask) memset(gmask, 0, (size_t)s->P);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int tile = 0; tile < T; tile++) {
+    const int ty = tile / s->gx, tx = tile % s->gx;
+    const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+    for (int ly = 0; ly < BLOCK_Y; ly++)
+      for (int lx = 0; lx < BLOCK_X; lx++) {
+        const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+        if (!(px < W && py < H)) continue;
+        float Tt = 1.0f;
+        uint8_t frag = 0;
+        for (uint32_t k = r0; k < r1; k++) {
+          const uint32_t id = s->point_list[k];
+          const float dx = s->means2D[2 * id] - (float)px, dy = s->means2D[2 * id + 1] - (float)py;
+          const float* co = s->conic_opacity + 4 * (size_t)id;
+          const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+          uint8_t f = 0;
+          if (fabsf(power) < 1e-5f) f = 1;
+          const float araw = co[3] * expf(fminf(power, 0.f));
+          const float alpha = fminf(0.99f, araw);
+          if (fabsf(alpha * 255.0f - 1.0f) < rel_eps) f = 1;
+          const float test_T = Tt * (1 - alpha);
+          if (alpha >= 1.0f / 255.0f && fabsf(test_T * 10000.0f - 1.0f) < rel_eps) f = 1;
+          if (f) { frag = 1; if (gmask) gmask[id] = 1; } /* benign race: every writer stores 1 */
+          if (power > 0.0f) continue;
+          if (alpha < 1.0f / 255.0f) continue;
+          if (test_T < 0.0001f) break;
+          Tt = test_T;
+        }
+        mask[(size_t)W * py + px] = frag;
+      }
+  }
+}
+
 static void orc_free_internal(OrcState* s) {
   free(s->depths); free(s->clamped); free(s->radii); free(s->means2D); free(s->cov3D);
   free(s->conic_opacity); free(s->rgb); free(s->tiles_touched); free(s->point_offsets);

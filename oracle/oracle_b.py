@@ -61,6 +61,8 @@ def lib():
             fn = getattr(L, "orc_" + name)
             fn.restype = rt
             fn.argtypes = [ctypes.c_void_p]
+        L.orc_fragile_mask.restype = None
+        L.orc_fragile_mask.argtypes = [ctypes.c_void_p, ctypes.c_float, c_u8p, c_u8p]
         L.orc_deform_apply_fwd.argtypes = [ctypes.c_int] + [c_fp] * 5
         L.orc_deform_apply_bwd.argtypes = [ctypes.c_int] + [c_fp] * 5
         _lib = L
@@ -113,6 +115,21 @@ class State:
             return np.zeros(shape)
         ptr = getattr(L, "orc_" + name)(self.handle)
         return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
+
+
+def fragile_mask(st: State, rel_eps: float = 2e-5):
+    """bool [H,W]: pixels whose walk passes within rel_eps of a hard threshold (see orc_fragile_mask)."""
+    m = np.zeros((st.H * st.W,), np.uint8)
+    lib().orc_fragile_mask(st.handle, float(rel_eps), m.ctypes.data_as(c_u8p), None)
+    return torch.from_numpy(m.reshape(st.H, st.W).astype(bool))
+
+
+def fragile_gaussians(st: State, rel_eps: float = 2e-5):
+    """bool [P]: Gaussians with at least one (pixel, Gaussian) pair within rel_eps of a hard threshold."""
+    m = np.zeros((st.H * st.W,), np.uint8)
+    g = np.zeros((max(st.P, 1),), np.uint8)
+    lib().orc_fragile_mask(st.handle, float(rel_eps), m.ctypes.data_as(c_u8p), g.ctypes.data_as(c_u8p))
+    return torch.from_numpy(g[:st.P].astype(bool))
 
 
 def set_threads(n: int):

@@ -195,7 +195,8 @@ def test_empty_inputs():
                                       rotations=torch.zeros(0, 4))
     assert state.num_rendered == 0 and c.abs().max() == 0 and (f.numel() == 0 or f.abs().max() == 0)
     # all Gaussians behind the camera: nothing rendered, image = background
-    sc["means3D"] = sc["means3D"] * 0 + torch.tensor(cam["camera_center"]) - 5.0
+    fwd = cam["world_view_transform"].reshape(-1)[[2, 6, 10]]  # world direction of +view-z
+    sc["means3D"] = sc["means3D"] * 0 + cam["camera_center"] - 3.0 * fwd
     c, f, r, g, state = util.run_oracle_b(sc, kw, dC, dF)
     assert state.num_rendered == 0 and (r == 0).all()
     assert torch.allclose(c, torch.tensor(kw["bg"]).reshape(3, 1, 1).expand_as(c))
