@@ -75,7 +75,7 @@ typedef struct MgsRasterArgs {
   const float* campos;          /* [3]                                                                */
   /* opaque workspaces, caller-allocated device memory (uint8 tensors in the reference) */
   void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M)            */
-  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H)      */
+  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H, F)   */
   void* img;     size_t img_bytes;      /* >= mgs_img_bytes(W, H)             */
 } MgsRasterArgs;
 
@@ -90,7 +90,7 @@ int mgs_get_option(const char* key);
  * (RAST/cuda_rasterizer/rasterizer_impl.h:65-72, rasterizer_impl.cu:155-194). */
 size_t mgs_geom_bytes(int P, int M);
 size_t mgs_img_bytes(int W, int H);
-size_t mgs_binning_bytes(int R, int W, int H);
+size_t mgs_binning_bytes(int R, int W, int H, int F);  /* F = feature channels rendered (0 if none) */
 size_t mgs_backward_scratch_bytes(int P, int M, int F);
 
 /* Forward, stage 1: preprocess + tile-count scan (K2, K3 of SURVEY.md 2b).

@@ -118,7 +118,7 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
         _lib.check(L.mgs_rasterize_forward_preprocess(ctypes.byref(a), radii.data_ptr(), ctypes.byref(nr), stream),
                    "rasterize_gaussians (preprocess)")
         R = int(nr.value)
-        binning = torch.empty((L.mgs_binning_bytes(R, W, H),), **u8)
+        binning = torch.empty((L.mgs_binning_bytes(R, W, H, F),), **u8)
         a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
         _lib.check(L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(),
                                                   _ptr(out_feat) if include_feature else None, stream),

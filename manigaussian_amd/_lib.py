@@ -42,7 +42,7 @@ _EXPORTS = {
     "mgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "mgs_geom_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
     "mgs_img_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
-    "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_backward_scratch_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_rasterize_forward_preprocess": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp,
                                                         ctypes.POINTER(c_i32), c_fp]),

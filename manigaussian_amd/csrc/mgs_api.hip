@@ -136,6 +136,9 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "bwd_reduce")) o.bwd_reduce = value;
   else if (!strcmp(key, "fast_exp")) o.fast_exp = value;
   else if (!strcmp(key, "profile")) o.profile = value;
+  else if (!strcmp(key, "render_mode")) o.render_mode = value;
+  else if (!strcmp(key, "chunk")) o.chunk = value;
+  else if (!strcmp(key, "exact_cull")) o.exact_cull = value;
   else { set_error("unknown option %s", key); return MGS_ERR_INVALID_ARG; }
   return MGS_OK;
 }
@@ -145,13 +148,27 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "bwd_reduce")) return o.bwd_reduce;
   if (!strcmp(key, "fast_exp")) return o.fast_exp;
   if (!strcmp(key, "profile")) return o.profile;
+  if (!strcmp(key, "render_mode")) return o.render_mode;
+  if (!strcmp(key, "chunk")) return o.chunk;
+  if (!strcmp(key, "exact_cull")) return o.exact_cull;
   set_error("unknown option %s", key);
   return MGS_ERR_INVALID_ARG;
 }
 
 size_t mgs_geom_bytes(int P, int M) { size_t t; carve_geom(nullptr, P, M, &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
-size_t mgs_binning_bytes(int R, int W, int H) { (void)W; (void)H; size_t t; carve_binning(nullptr, R, &t); return t; }
+static int chunk_size() {  // 0 when the chunk-parallel render is off
+  const Options& o = options();
+  if (o.render_mode != 1 && o.render_mode != 2) return 0;
+  int ch = o.chunk < 64 ? 64 : o.chunk;
+  return (ch + 63) / 64 * 64;
+}
+static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+size_t mgs_binning_bytes(int R, int W, int H, int F) {
+  size_t t;
+  carve_binning(nullptr, R, num_tiles(W, H), F, chunk_size(), nullptr, &t);
+  return t;
+}
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
 
 int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
@@ -214,15 +231,17 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
   }
   if (R < 0 || !radii) { set_error("num_rendered < 0 or radii NULL"); return MGS_ERR_INVALID_ARG; }
   if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
-      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H)) {
+      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H, F)) {
     set_error("workspace too small (geom %zu/%zu, img %zu/%zu, binning %zu/%zu)", a->geom_bytes,
               mgs_geom_bytes(a->P, a->M), a->img_bytes, mgs_img_bytes(a->W, a->H), a->binning_bytes,
-              mgs_binning_bytes(R, a->W, a->H));
+              mgs_binning_bytes(R, a->W, a->H, F));
     return MGS_ERR_WORKSPACE;
   }
   GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
-  BinView b = carve_binning(a->binning, R, nullptr);
+  ChunkView cv;
+  const int CH = chunk_size();
+  BinView b = carve_binning(a->binning, R, num_tiles(a->W, a->H), F, CH, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   { StageTimer t(ST_DUPLICATE, stream);
     MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, options().tight_bins, stream),
@@ -233,12 +252,19 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
     MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
   RenderArgs r;
   r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce;
+  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull;
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
   { StageTimer t(ST_RENDER_FWD, stream);
-    MGS_STAGE(launch_render_fwd(r, b, im, out_color, out_feature, stream), "render forward", a->debug, stream); }
+    if (CH > 0 && options().render_mode == 2)
+      MGS_STAGE(launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (coop)",
+                a->debug, stream);
+    else if (CH > 0)
+      MGS_STAGE(launch_render_fwd_chunked(r, b, im, cv, out_color, out_feature, stream), "render forward (chunked)",
+                a->debug, stream);
+    else
+      MGS_STAGE(launch_render_fwd(r, b, im, out_color, out_feature, stream), "render forward", a->debug, stream); }
   return MGS_OK;
 }
 
@@ -259,13 +285,15 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   }
   if (!scratch || scratch_bytes < mgs_backward_scratch_bytes(a->P, a->M, F) || !a->geom ||
       a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
-      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H)) {
+      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H, F)) {
     set_error("backward: workspace too small");
     return MGS_ERR_WORKSPACE;
   }
   GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
-  BinView b = carve_binning(a->binning, R, nullptr);
+  ChunkView cv;
+  const int CH = chunk_size();
+  BinView b = carve_binning(a->binning, R, num_tiles(a->W, a->H), F, CH, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, a->P, a->M, F, nullptr);
   const size_t P = (size_t)a->P;
   // accumulators the render backward adds into
@@ -280,13 +308,20 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   if (R > 0) {
     RenderArgs r;
     r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce;
+    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull;
     r.bg = a->background;
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;
     StageTimer t(ST_RENDER_BWD, stream);
-    MGS_STAGE(launch_render_bwd(r, b, im, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
-              "render backward", a->debug, stream);
+    if (CH > 0 && options().render_mode == 2)
+      MGS_STAGE(launch_render_bwd_coop(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
+                                       stream), "render backward (coop)", a->debug, stream);
+    else if (CH > 0)
+      MGS_STAGE(launch_render_bwd_chunked(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
+                                          stream), "render backward (chunked)", a->debug, stream);
+    else
+      MGS_STAGE(launch_render_bwd(r, b, im, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
+                "render backward", a->debug, stream);
   }
   BwdPreArgs p;
   p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;

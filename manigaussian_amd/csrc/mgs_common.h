@@ -63,6 +63,19 @@ struct BinView {
   size_t sort_temp_bytes;
 };
 
+// Per-(tile, 8x8 block, chunk) state of the chunk-parallel render (mgs_render_chunked.hip).
+struct ChunkView {
+  int CH;                 // entries per chunk
+  int max_chunks;         // upper bound of sum_t ceil(len_t / CH) = R/CH + T
+  uint32_t* chunk_base;   // [T+2]
+  uint32_t* last_chunk;   // [T*4*64]  per pixel: number of chunks visited by the forward
+  float* Tprod;           // [items][64]
+  float* T_end;           // [items][64]
+  uint32_t* last_pos;     // [items][64]
+  float* q;               // [items][64]
+  float* partial;         // [items][3+F][64]
+};
+
 size_t scan_temp_bytes(int P);
 size_t sort_temp_bytes(int R);
 
@@ -99,7 +112,7 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   return v;
 }
 
-inline BinView carve_binning(void* p, int R, size_t* total) {
+inline BinView carve_binning(void* p, int R, int T, int F, int CH, ChunkView* cv, size_t* total) {
   Carver c(p);
   BinView b;
   size_t Ra = R > 0 ? (size_t)R : 1;
@@ -110,6 +123,20 @@ inline BinView carve_binning(void* p, int R, size_t* total) {
   b.inst = c.take<float4>(2 * Ra);
   b.sort_temp_bytes = sort_temp_bytes((int)Ra);
   b.sort_temp = c.take<char>(b.sort_temp_bytes);
+  if (CH > 0) {  // chunk-parallel render state
+    ChunkView v;
+    v.CH = CH;
+    v.max_chunks = (int)((Ra + (size_t)CH - 1) / (size_t)CH) + T;
+    const size_t items = 4 * (size_t)(8 * ((v.max_chunks + 7) / 8));
+    v.chunk_base = c.take<uint32_t>((size_t)T + 2);
+    v.last_chunk = c.take<uint32_t>((size_t)T * 4 * 64);
+    v.Tprod = c.take<float>(items * 64);
+    v.T_end = c.take<float>(items * 64);
+    v.last_pos = c.take<uint32_t>(items * 64);
+    v.q = c.take<float>(items * 64);
+    v.partial = c.take<float>(items * (size_t)(3 + F) * 64);
+    if (cv) *cv = v;
+  }
   if (total) *total = c.total();
   return b;
 }
@@ -130,10 +157,14 @@ inline BwdScratch carve_bwd(void* p, int P, int M, int F, size_t* total) {
 
 // ---- run-time options (mgs_set_option) ----------------------------------------------------------
 struct Options {
-  int tight_bins = 0;      // 1: drop (Gaussian,tile) instances whose alpha>=1/255 footprint misses the tile
+  int tight_bins = 1;      // 1: drop (Gaussian,tile) instances whose alpha>=1/255 footprint misses the tile
   int bwd_reduce = 1;      // 0: shuffle reference reduction, 1: butterfly (permlane swap + DPP)
-  int fast_exp = 0;        // 1: v_exp_f32 based exp in the render kernels
+  int fast_exp = 1;        // 1: v_exp_f32 based exp in the render kernels (rel. error ~2e-7 |x|), 0: ocml expf
   int profile = 0;         // 0: off, 1: hipEvents around the render backward only, 2: around every stage
+  // The next two shape the binning workspace: do not change them between a forward and its backward.
+  int render_mode = 2;     // 0: one wave per 8x8 block walks the whole tile list, 1: chunk items, 2: cooperative
+  int chunk = 64;          // entries per chunk (multiple of 64) for render_mode 1 and 2
+  int exact_cull = 1;      // render_mode 2: exact ellipse-vs-block cull on top of the bbox cull
 };
 Options& options();
 
@@ -157,7 +188,7 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, c
                                uint8_t* present, hipStream_t s);
 
 struct RenderArgs {
-  int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, bwd_reduce;
+  int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, bwd_reduce, exact_cull;
   const float* bg;
   const float* colors;   // [P,3] colors_precomp or geom.rgb
   const float* feats;    // [P,F]
@@ -167,6 +198,18 @@ hipError_t launch_render_fwd(const RenderArgs& r, const BinView& b, const ImgVie
 hipError_t launch_render_bwd(const RenderArgs& r, const BinView& b, const ImgView& im, const float* dL_dcolor_px,
                              const float* dL_dfeat_px, float* acc8, float* dL_dcolors, float* dL_dfeat,
                              hipStream_t s);
+
+hipError_t launch_render_fwd_chunked(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                     float* out_color, float* out_feat, hipStream_t s);
+hipError_t launch_render_bwd_chunked(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                     const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8,
+                                     float* dL_dcolors, float* dL_dfeat, hipStream_t s);
+
+hipError_t launch_render_fwd_coop(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                  float* out_color, float* out_feat, hipStream_t s);
+hipError_t launch_render_bwd_coop(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                  const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
+                                  float* dL_dfeat, hipStream_t s);
 
 struct BwdPreArgs {
   int P, D, M, W, H;

@@ -1,0 +1,526 @@
+// mgs_render_coop.hip -- cooperative chunk-parallel alpha-composite render (forward + backward), gfx950.
+//
+// Results: the reference's renderCUDA forward/backward (RAST/cuda_rasterizer/forward.cu:262-398,
+// backward.cu:399-593) -- same per-pixel test order and stop rule -- see mgs_render.hip for the semantics.
+//
+// Decomposition (why it is not the reference's "one 256-thread block per tile"): at 128x128 there are 64
+// tiles but 256 CUs / 1024 SIMDs, and a pixel's walk is a serial chain thousands of entries long.  Here a
+// workgroup of NW waves owns one 8x8 pixel block of a tile; the tile's depth-sorted list is cut into chunks of
+// CH entries and the NW waves sweep NW chunks per round:
+//   phase A  every wave multiplies out (1 - alpha) over ITS chunk for its 64 pixels           -> LDS
+//   prefix   T_in(chunk) = T_round * prod of the earlier waves' products, always in chunk order, so every
+//            consumer (forward, backward) sees bit-identical transmittances
+//   phase B  every wave blends its chunk from T_in with the exact reference test order; pixels whose T_in is
+//            already < 1e-4 are finished (the stop rule is monotone in T).  The chunk's partial colour sums,
+//            T_end and last blended position are kept for the backward.
+//   the round loop ends as soon as every pixel of the block has terminated (typically after 1-2 rounds), so
+//   the entries behind the termination depth are never touched.
+// Backward: the same workgroup shape; per chunk the boundary state of the reference's back-to-front
+// recurrences is rebuilt from what the forward kept: T = T_end, and the scalar accum_rec . dL_dpixel equals
+// (sum over later visited chunks of dL_dpixel . partial) / T_end.  Chunks are then independent.
+#include "mgs_render_common.h"
+
+namespace mgs {
+
+// conservative EXACT-shape cull: does {q(d) <= tau} (tau = 2 ln(255 o), inflated) reach the pixel rectangle?
+// bbox test first; then the minimum of the quadratic form over the rectangle (on the boundary unless the
+// centre is inside).  Degenerate conics (marked by hx >= 1e5 in the preprocess) are never culled.
+__device__ __forceinline__ bool reaches_block(const float4& g0, const float4& g1, float bxmin, float bxmax,
+                                              float bymin, float bymax) {
+  if (!overlaps_block(g0, g1, bxmin, bxmax, bymin, bymax)) return false;
+  if (g1.z >= 1e5f) return true;
+  const float dx0 = bxmin - g0.x, dx1 = bxmax - g0.x, dy0 = bymin - g0.y, dy1 = bymax - g0.y;
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  const float cx = g0.z, cy = g0.w, cz = g1.x;
+  const float tau = 2.0f * __logf(fmaxf(g1.y * 255.0f, 1.0f)) * 1.001f + 2e-3f;
+  const float icz = 1.0f / cz, icx = 1.0f / cx;
+  float best = 3.0e38f;
+  {
+    const float dy = fminf(fmaxf(-cy * dx0 * icz, dy0), dy1);
+    best = fminf(best, cx * dx0 * dx0 + 2.f * cy * dx0 * dy + cz * dy * dy);
+  }
+  {
+    const float dy = fminf(fmaxf(-cy * dx1 * icz, dy0), dy1);
+    best = fminf(best, cx * dx1 * dx1 + 2.f * cy * dx1 * dy + cz * dy * dy);
+  }
+  {
+    const float dx = fminf(fmaxf(-cy * dy0 * icx, dx0), dx1);
+    best = fminf(best, cx * dx * dx + 2.f * cy * dx * dy0 + cz * dy0 * dy0);
+  }
+  {
+    const float dx = fminf(fmaxf(-cy * dy1 * icx, dx0), dx1);
+    best = fminf(best, cx * dx * dx + 2.f * cy * dx * dy1 + cz * dy1 * dy1);
+  }
+  return !(best > tau);
+}
+
+struct PixBlk {
+  int px, py;
+  bool inside;
+  float pxf, pyf, bxmin, bxmax, bymin, bymax;
+};
+__device__ __forceinline__ PixBlk pix_blk(const RenderArgs& r, int tile, int sub, int lane) {
+  PixBlk p;
+  const int tx = tile % r.tiles_x, ty = tile / r.tiles_x;
+  const int bx0 = tx * TILE + (sub & 1) * SUB, by0 = ty * TILE + (sub >> 1) * SUB;
+  p.px = bx0 + (lane & 7);
+  p.py = by0 + (lane >> 3);
+  p.inside = p.px < r.W && p.py < r.H;
+  p.pxf = (float)p.px; p.pyf = (float)p.py;
+  p.bxmin = (float)bx0; p.bxmax = (float)min(bx0 + SUB - 1, r.W - 1);
+  p.bymin = (float)by0; p.bymax = (float)min(by0 + SUB - 1, r.H - 1);
+  return p;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ bool cull_ok(const float4& g0, const float4& g1, const PixBlk& p) {
+  if constexpr (EXACT) return reaches_block(g0, g1, p.bxmin, p.bxmax, p.bymin, p.bymax);
+  else return overlaps_block(g0, g1, p.bxmin, p.bxmax, p.bymin, p.bymax);
+}
+
+// wave-private LDS hand-off (all LDS traffic of one wave executes in order; only the compiler must not reorder)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// storage index of chunk c of a tile whose list starts at x: floor(x/CH) + tile + c  (collision-free and
+// bounded by R/CH + T, so no prefix table is needed)
+__device__ __forceinline__ size_t chunk_slot(uint32_t range_x, int tile, int CH, uint32_t c, int sub) {
+  return ((size_t)(range_x / (uint32_t)CH) + (size_t)tile + c) * 4 + (size_t)sub;
+}
+
+// ------------------------------------------- forward ------------------------------------------------
+template <int F, bool FAST, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH, const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list,
+                                                            const float4* __restrict__ inst, float* __restrict__ T_end,
+                                                            uint32_t* __restrict__ last_pos, float* __restrict__ partial,
+                                                            float* __restrict__ final_T, uint32_t* __restrict__ last_chunk,
+                                                            float* __restrict__ out_color, float* __restrict__ out_feat) {
+  constexpr int ROW4 = Row<F>::ROW4;
+  constexpr int NCH = F + 3;
+  constexpr int STAGE4 = 64 * ROW4;                         // float4 per wave
+  __shared__ float4 lds[NW * STAGE4];
+  __shared__ float Tp[NW][64];
+  __shared__ float red_Tf[64];
+  __shared__ uint32_t red_vis[64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tile, sub;
+  map_block(blockIdx.x, tile, sub);
+  if (tile >= r.tiles_x * r.tiles_y) return;
+  const PixBlk p = pix_blk(r, tile, sub, lane);
+  const uint2 rng = ranges[tile];
+  const uint32_t len = rng.y - rng.x;
+  const uint32_t nch = (len + (uint32_t)CH - 1u) / (uint32_t)CH;
+  const bool use_feat = (F > 0) && r.include_feature;
+  float4* stage = lds + w * STAGE4;
+
+  float Tround = 1.0f;
+  uint32_t my_vis = 0;
+  float my_Tf = 1.0f;
+
+  for (uint32_t r0 = 0; r0 < nch; r0 += NW) {
+    const uint32_t c = r0 + (uint32_t)w;
+    const bool has = c < nch;
+    const uint32_t e0 = rng.x + c * (uint32_t)CH;
+    const uint32_t e1 = min(e0 + (uint32_t)CH, rng.y);
+    // ---- phase A: transmittance product of this chunk ----
+    float tp = 1.0f;
+    if (has) {
+      for (uint32_t k0 = e0; k0 < e1; k0 += 64) {
+        const uint32_t e = k0 + lane;
+        const bool valid = e < e1;
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+        if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; }
+        unsigned long long mask = ballot(valid && cull_ok<EXACT>(g0, g1, p));
+        while (mask) {
+          const int j = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+          const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+          const float op = bcast_lane(g1.y, j);
+          const float dx = ex - p.pxf, dy = ey - p.pyf;
+          const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+          const float alpha = fminf(0.99f, op * exp_<FAST>(power));
+          const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
+          tp = skip ? tp : tp * (1.0f - alpha);
+        }
+      }
+    }
+    Tp[w][lane] = tp;
+    __syncthreads();
+    // ---- prefix in chunk order (identical arithmetic in every wave) ----
+    float T = Tround;
+    for (int w2 = 0; w2 < w; w2++) T *= Tp[w2][lane];
+    float Tnext = T;
+    for (int w2 = w; w2 < NW; w2++) Tnext *= Tp[w2][lane];
+    // ---- phase B: blend this chunk ----
+    const bool live = has && p.inside && !(T < 0.0001f);
+    if (ballot(live) != 0) {
+      bool done = !live;
+      float C[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; i++) C[i] = 0.f;
+      uint32_t last = 0;
+      for (uint32_t k0 = e0; k0 < e1; k0 += 64) {
+        if (ballot(!done) == 0) break;
+        const uint32_t e = k0 + lane;
+        const bool valid = e < e1;
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+        if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; }
+        const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
+        unsigned long long mask = ballot(surv);
+        if (mask == 0) continue;
+        wave_lds_sync();
+        if (surv) stage_row<F>(stage, lane, point_list[e], r.colors, use_feat ? r.feats : nullptr);
+        wave_lds_sync();
+        while (mask) {
+          const int j = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+          const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+          const float op = bcast_lane(g1.y, j);
+          const float dx = ex - p.pxf, dy = ey - p.pyf;
+          const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+          const float alpha = fminf(0.99f, op * exp_<FAST>(power));
+          const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
+          const float test_T = T * (1.0f - alpha);
+          const bool cand = !done && !skip;
+          const bool term = cand && (test_T < 0.0001f);
+          done = done || term;
+          const bool blend = cand && !term;
+          if (ballot(blend) == 0) continue;
+          const float wgt = blend ? alpha * T : 0.f;
+          const float4* row = stage + j * ROW4;
+          if constexpr (F > 0) {
+            if (use_feat) {
+              if constexpr (F % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < F / 4; i++) {
+                  const float4 v = row[i];
+                  C[3 + 4 * i] += v.x * wgt; C[3 + 4 * i + 1] += v.y * wgt;
+                  C[3 + 4 * i + 2] += v.z * wgt; C[3 + 4 * i + 3] += v.w * wgt;
+                }
+              } else {
+                const float* rf = reinterpret_cast<const float*>(row);
+#pragma unroll
+                for (int i = 0; i < F; i++) C[3 + i] += rf[i] * wgt;
+              }
+            }
+          }
+          {
+            const float* rf = reinterpret_cast<const float*>(row);
+            C[0] += rf[F] * wgt; C[1] += rf[F + 1] * wgt; C[2] += rf[F + 2] * wgt;
+          }
+          T = blend ? test_T : T;
+          last = blend ? (k0 - e0) + (uint32_t)j + 1u : last;
+        }
+      }
+      const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+      T_end[slot * 64 + lane] = T;
+      last_pos[slot * 64 + lane] = last;
+      float* pp = partial + slot * NCH * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
+      if (live) { my_vis = c + 1; my_Tf = T; }
+    }
+    __syncthreads();  // Tp is rewritten next round
+    Tround = Tnext;
+    if (ballot(p.inside && !(Tround < 0.0001f)) == 0) break;
+  }
+
+  // ---- image = sum of the visited chunks' partials, in chunk order (deterministic); channels split over waves ----
+  if (w == 0) { red_vis[lane] = 0; red_Tf[lane] = 1.0f; }
+  __syncthreads();
+  if (my_vis > 0) atomicMax(&red_vis[lane], my_vis);
+  __syncthreads();
+  const uint32_t vis = red_vis[lane];
+  if (my_vis > 0 && my_vis == vis) red_Tf[lane] = my_Tf;  // exactly one wave owns the last visited chunk
+  __syncthreads();  // also makes this workgroup's partial[] stores visible to all its waves
+  const float Tf = red_Tf[lane];
+  const uint32_t vismax = wave_umax(vis);
+  const size_t HW = (size_t)r.H * r.W;
+  const size_t pix = (size_t)p.py * r.W + p.px;
+  for (int ch = w; ch < NCH; ch += NW) {
+    if (ch >= 3 && !use_feat) break;
+    float sum = 0.f;
+    for (uint32_t c = 0; c < vismax; c++) {
+      const float v = partial[chunk_slot(rng.x, tile, CH, c, sub) * NCH * 64 + (size_t)ch * 64 + lane];
+      sum += (c < vis) ? v : 0.f;
+    }
+    if (p.inside) {
+      if (ch < 3) out_color[ch * HW + pix] = sum + Tf * r.bg[ch];
+      else out_feat[(ch - 3) * HW + pix] = sum;
+    }
+  }
+  if (w == 0) {
+    last_chunk[((size_t)tile * 4 + sub) * 64 + lane] = vis;
+    if (p.inside) final_T[pix] = Tf;
+  }
+}
+
+// ------------------------------------------- backward -----------------------------------------------
+template <int F, bool FAST, bool EXACT, int RED, int NW>
+__global__ void __launch_bounds__(NW * 64) coop_bwd_kernel(RenderArgs r, int CH, const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list,
+                                                            const float4* __restrict__ inst,
+                                                            const uint32_t* __restrict__ last_chunk,
+                                                            const float* __restrict__ T_end,
+                                                            const uint32_t* __restrict__ last_pos,
+                                                            const float* __restrict__ partial, float* __restrict__ q,
+                                                            const float* __restrict__ final_T,
+                                                            const float* __restrict__ dL_dpix,
+                                                            const float* __restrict__ dL_dpix_F, float* __restrict__ acc8,
+                                                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat) {
+  constexpr int ROW4 = Row<F>::ROW4;
+  constexpr int NCH = F + 3;
+  constexpr int FP = F > 0 ? next_pow2(F) : 1;
+  __shared__ float4 lds[NW * 64 * ROW4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tile, sub;
+  map_block(blockIdx.x, tile, sub);
+  if (tile >= r.tiles_x * r.tiles_y) return;
+  const uint32_t lc = last_chunk[((size_t)tile * 4 + sub) * 64 + lane];
+  const uint32_t lcmax = wave_umax(lc);
+  if (lcmax == 0) return;
+  const PixBlk p = pix_blk(r, tile, sub, lane);
+  const uint2 rng = ranges[tile];
+  const bool use_feat = (F > 0) && r.include_feature;
+  const size_t HW = (size_t)r.H * r.W;
+  const size_t pix = (size_t)p.py * r.W + p.px;
+  float4* stage = lds + w * 64 * ROW4;
+  const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+
+  const float T_final = any ? final_T[pix] : 0.f;
+  float dLc[3] = {0.f, 0.f, 0.f};
+  float dLf[F > 0 ? F : 1];
+#pragma unroll
+  for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
+  if (any) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[ch * HW + pix];
+    if constexpr (F > 0) {
+      if (use_feat) {
+#pragma unroll
+        for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[ch * HW + pix];
+      }
+    }
+  }
+  const float bgdot = r.bg[0] * dLc[0] + r.bg[1] * dLc[1] + r.bg[2] * dLc[2];
+
+  // ---- phase 0: q[c] = dL . partial[c] for the visited chunks ----
+  for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
+    const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+    float s = 0.f;
+    if (c < lc) {
+      const float* pp = partial + slot * NCH * 64 + lane;
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) s += dLc[ch] * pp[ch * 64];
+      if constexpr (F > 0) {
+        if (use_feat) {
+#pragma unroll
+          for (int ch = 0; ch < F; ch++) s += dLf[ch] * pp[(3 + ch) * 64];
+        }
+      }
+    }
+    q[slot * 64 + lane] = s;
+  }
+  __syncthreads();  // q (global, this workgroup only) is visible to the other waves
+
+  const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.H;
+  // ---- phase 1: independent chunks ----
+  for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
+    const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+    const uint32_t last = (c < lc) ? last_pos[slot * 64 + lane] : 0u;
+    const uint32_t kmax = wave_umax(last);
+    if (kmax == 0) continue;
+    const bool live = last > 0;
+    float B = 0.f;
+    for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
+      const float v = q[chunk_slot(rng.x, tile, CH, c2, sub) * 64 + lane];
+      B += (live && c2 < lc) ? v : 0.f;
+    }
+    float T = live ? T_end[slot * 64 + lane] : 1.0f;
+    float A = live ? B / T : 0.f, last_alpha = 0.f, last_D = 0.f;
+    const uint32_t e0 = rng.x + c * (uint32_t)CH;
+    const int nb = (int)((kmax + 63u) / 64u);
+    for (int bi = nb - 1; bi >= 0; --bi) {
+      const uint32_t e = e0 + (uint32_t)bi * 64u + lane;
+      const uint32_t pos_l = (uint32_t)bi * 64u + lane + 1u;
+      const bool valid = e < rng.y && pos_l <= kmax;
+      float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+      if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; }
+      const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
+      unsigned long long mask = ballot(surv);
+      if (mask == 0) continue;
+      uint32_t id_l = 0;
+      wave_lds_sync();
+      if (surv) {
+        id_l = point_list[e];
+        stage_row<F>(stage, lane, id_l, r.colors, use_feat ? r.feats : nullptr);
+      }
+      wave_lds_sync();
+      while (mask) {
+        const int j = 63 - __builtin_clzll(mask);
+        mask &= ~(1ull << j);
+        const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+        const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+        const float op = bcast_lane(g1.y, j);
+        const uint32_t pos = (uint32_t)bi * 64u + (uint32_t)j + 1u;
+        const float dx = ex - p.pxf, dy = ey - p.pyf;
+        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+        const float G = exp_<FAST>(power);
+        const float alpha = fminf(0.99f, op * G);
+        const bool active = pos <= last && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        if (ballot(active) == 0) continue;
+
+        const float4* row = stage + j * ROW4;
+        const float* rf = reinterpret_cast<const float*>(row);
+        float D = rf[F] * dLc[0] + rf[F + 1] * dLc[1] + rf[F + 2] * dLc[2];
+        if constexpr (F > 0) {
+          if (use_feat) {
+            if constexpr (F % 4 == 0) {
+#pragma unroll
+              for (int i = 0; i < F / 4; i++) {
+                const float4 v = row[i];
+                D += v.x * dLf[4 * i] + v.y * dLf[4 * i + 1] + v.z * dLf[4 * i + 2] + v.w * dLf[4 * i + 3];
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < F; i++) D += rf[i] * dLf[i];
+            }
+          }
+        }
+        const float one_m = 1.f - alpha;
+        const float Tn = T / one_m;
+        const float An = last_alpha * last_D + (1.f - last_alpha) * A;
+        float dL_dalpha = (D - An) * Tn;
+        dL_dalpha += (-T_final / one_m) * bgdot;
+        if (active) { T = Tn; A = An; last_alpha = alpha; last_D = D; }
+        const float wa = active ? alpha * Tn : 0.f;
+        const float dL_dG = op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * cx - gdy * cy;
+        const float dG_ddely = -gdy * cz - gdx * cy;
+        float s[16];
+        s[0] = active ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
+        s[1] = active ? dL_dG * dG_ddely * ddely_dy : 0.f;
+        s[2] = active ? -0.5f * gdx * dx * dL_dG : 0.f;
+        s[3] = active ? -0.5f * gdx * dy * dL_dG : 0.f;
+        s[4] = active ? -0.5f * gdy * dy * dL_dG : 0.f;
+        s[5] = active ? G * dL_dalpha : 0.f;
+        s[6] = wa * dLc[0]; s[7] = wa * dLc[1]; s[8] = wa * dLc[2];
+#pragma unroll
+        for (int i = 9; i < 16; i++) s[i] = 0.f;
+        const uint32_t id = bcast_lane_u32(id_l, j);
+
+        if constexpr (RED == 1) {
+          bfly_reduce<16>(s, lane);
+          {
+            const int idx = (lane >> 2) & 15;
+            if ((lane & 3) == 0 && idx < 9) {
+              float* dst = idx < 6 ? (acc8 + (size_t)id * 8 + idx) : (dL_dcolors + (size_t)id * 3 + (idx - 6));
+              unsafeAtomicAdd(dst, s[0]);
+            }
+          }
+          if constexpr (F > 0) {
+            if (use_feat) {
+              float f[FP];
+#pragma unroll
+              for (int i = 0; i < FP; i++) f[i] = (i < F) ? wa * dLf[i < F ? i : 0] : 0.f;
+              bfly_reduce<FP>(f, lane);
+              constexpr int SH = 6 - ilog2(FP);
+              const int idx = (lane >> SH) & (FP - 1);
+              if ((lane & ((1 << SH) - 1)) == 0 && idx < F) unsafeAtomicAdd(dL_dfeat + (size_t)id * F + idx, f[0]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            const float t = wave_sum_shfl(s[i]);
+            if (lane == 0) {
+              float* dst = i < 6 ? (acc8 + (size_t)id * 8 + i) : (dL_dcolors + (size_t)id * 3 + (i - 6));
+              unsafeAtomicAdd(dst, t);
+            }
+          }
+          if constexpr (F > 0) {
+            if (use_feat) {
+#pragma unroll
+              for (int i = 0; i < F; i++) {
+                const float t = wave_sum_shfl(wa * dLf[i]);
+                if (lane == 0) unsafeAtomicAdd(dL_dfeat + (size_t)id * F + i, t);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------- dispatch ------------------------------------------------
+template <int F>
+constexpr int waves_for() { return F <= 32 ? 16 : 8; }  // 64 staged rows per wave must fit the 160 KB LDS
+
+template <int F>
+static hipError_t fwd_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, float* oc,
+                        float* of, hipStream_t s) {
+  constexpr int NW = waves_for<F>();
+  const int T = r.tiles_x * r.tiles_y;
+  const int grid = ((T + 7) / 8) * 32;
+#define MGS_CF(FAST, EXACT)                                                                                         \
+  hipLaunchKernelGGL((coop_fwd_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges,    \
+                     b.point_list, b.inst, cv.T_end, cv.last_pos, cv.partial, im.final_T, cv.last_chunk, oc, of)
+  if (r.fast_exp) { if (r.exact_cull) MGS_CF(true, true); else MGS_CF(true, false); }
+  else            { if (r.exact_cull) MGS_CF(false, true); else MGS_CF(false, false); }
+#undef MGS_CF
+  return hipGetLastError();
+}
+
+template <int F>
+static hipError_t bwd_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, const float* dc,
+                        const float* df, float* acc8, float* dcol, float* dfeat, hipStream_t s) {
+  constexpr int NW = waves_for<F>();
+  const int T = r.tiles_x * r.tiles_y;
+  const int grid = ((T + 7) / 8) * 32;
+#define MGS_CB(FAST, EXACT, RED)                                                                                     \
+  hipLaunchKernelGGL((coop_bwd_kernel<F, FAST, EXACT, RED, NW>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges, \
+                     b.point_list, b.inst, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, \
+                     acc8, dcol, dfeat)
+  if (r.bwd_reduce == 0) {
+    if (r.fast_exp) MGS_CB(true, true, 0); else MGS_CB(false, true, 0);
+  } else if (r.fast_exp) {
+    if (r.exact_cull) MGS_CB(true, true, 1); else MGS_CB(true, false, 1);
+  } else {
+    if (r.exact_cull) MGS_CB(false, true, 1); else MGS_CB(false, false, 1);
+  }
+#undef MGS_CB
+  return hipGetLastError();
+}
+
+hipError_t launch_render_fwd_coop(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                  float* out_color, float* out_feat, hipStream_t s) {
+  const int F = r.include_feature ? r.F : 0;
+  switch (F) {
+#define X(N) case N: return fwd_F<N>(r, b, im, cv, out_color, out_feat, s);
+    MGS_FOR_EACH_F(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_render_bwd_coop(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                  const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
+                                  float* dL_dfeat, hipStream_t s) {
+  const int F = r.include_feature ? r.F : 0;
+  switch (F) {
+#define X(N) case N: return bwd_F<N>(r, b, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, s);
+    MGS_FOR_EACH_F(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mgs

@@ -1,5 +1,5 @@
-"""First-contact GPU diagnostic: self-test, parity vs Oracle B for a few configs and both backward
-reduction variants, rough timings.  Run on the GPU box:  python scripts/gpu_check.py"""
+"""GPU diagnostic: self-test, parity vs Oracle B across kernel variants, per-stage timings at the headline
+config.  Run on the GPU box:  python scripts/gpu_check.py [quick]"""
 import os
 import sys
 import time
@@ -12,45 +12,86 @@ from manigaussian_amd import _lib
 import util
 
 
+def parity(variants, cases):
+    for v in variants:
+        for k, val in v.items():
+            _lib.set_option(k, val)
+        for c in cases:
+            sc, cam, kw, dC, dF = util.scene_case(**c)
+            inc = c.get("include_feature", True)
+            cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
+            ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, c.get("sh_degree", 1), inc, c.get("bg", (0.1, 0.2, 0.3)))
+            ec = util.image_errors(ch, cr, st)
+            ef = util.image_errors(fh, fr, st) if inc else (0, 0, 0)
+            errs, frac = util.grad_errors_split(gh, gr, st)
+            wr = max((r / (m + 1e-30), k) for k, (r, f, m) in errs.items() if m > 0)
+            wf = max((f / (m + 1e-30), k) for k, (r, f, m) in errs.items() if m > 0)
+            ok = ec[0] <= 1e-4 and ef[0] <= 1e-4 and wr[0] <= 1e-3 and wf[0] <= 1e-2 and bool((rh == rr).all())
+            print(f"{'OK ' if ok else 'BAD'} {v} {c}: R={st.num_rendered} color {ec[0]:.1e}/{ec[1]:.1e} "
+                  f"feat {ef[0]:.1e}/{ef[1]:.1e} grad robust {wr[0]:.1e} ({wr[1]}) fragile {wf[0]:.1e} ({wf[1]})")
+
+
+def timing(variants, P=100000, F=32, W=128, steps=30):
+    from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from manigaussian_amd import synthetic as syn
+    dev = torch.device("cuda:0")
+    sc = syn.make_scene(P, F=F, M=4, seed=0)
+    cam = syn.circle_cameras(8, W, W, negative_focal=True)[0]
+    d = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+    dC, dF = [t.to(dev) for t in syn.make_cotangents(W, W, F)]
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+
+    def step():
+        c, f, r = rast(d["means3D"], m2d, d["opacities"], shs=d["shs"], language_feature_precomp=d["language_feature"],
+                       scales=d["scales"], rotations=d["rotations"])
+        torch.autograd.backward([c, f], [dC, dF])
+        for t in d.values():
+            t.grad = None
+        m2d.grad = None
+
+    for v in variants:
+        for k, val in v.items():
+            _lib.set_option(k, val)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        _lib.profile_read(True)
+        _lib.set_option("profile", 2)
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        _lib.set_option("profile", 0)
+        st = {k: ms / max(c, 1) * 1e3 for k, (ms, c) in _lib.profile_read(True).items()}
+        print(f"{v}: wall {wall:.3f} ms/step | " + " ".join(f"{k}={x:.0f}us" for k, x in st.items()) +
+              f" | sum={sum(st.values()):.0f}us")
+
+
 def main():
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     L = _lib.lib()
     print("device:", torch.cuda.get_device_name(0))
     rc = L.mgs_selftest(None)
     print("selftest rc =", rc, _lib.last_error() if rc else "")
     cases = [dict(P=3000, F=3), dict(P=3000, F=32), dict(P=3000, F=3, neg=False, colors_precomp=True),
-             dict(P=20000, F=32), dict(P=2000, F=5), dict(P=2000, F=3, include_feature=False)]
-    for red in (0, 1):
-        _lib.set_option("bwd_reduce", red)
-        for tb in (0, 1):
-            _lib.set_option("tight_bins", tb)
-            for c in cases:
-                sc, cam, kw, dC, dF = util.scene_case(**c)
-                inc = c.get("include_feature", True)
-                cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
-                t0 = time.time()
-                ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, inc, (0.1, 0.2, 0.3))
-                dt = time.time() - t0
-                ec = (ch - cr).abs().max().item()
-                ef = (fh - fr).abs().max().item() if inc else 0.0
-                errs = util.grad_errors(gh, gr)
-                worst = max((e / (m + 1e-30), k) for k, (e, m) in errs.items() if m > 0)
-                print(f"red={red} tight={tb} {c}: R={st.num_rendered} radii_eq={bool((rh == rr).all())} "
-                      f"color {ec:.2e} feat {ef:.2e} worst grad rel-to-max {worst[0]:.2e} ({worst[1]}) [{dt*1e3:.0f} ms]")
-                if worst[0] > 1e-3 or ec > 1e-4:
-                    for k, (e, m) in errs.items():
-                        print(f"      {k}: err {e:.3e} max {m:.3e}")
-    # timing at the headline config
+             dict(P=20000, F=32), dict(P=2000, F=5), dict(P=2000, F=3, include_feature=False),
+             dict(P=3000, F=3, cov3d=True, W=72, H=40), dict(P=30000, F=32, W=64, H=64)]
+    variants = [dict(render_mode=2, chunk=128, tight_bins=1, exact_cull=1, fast_exp=0, bwd_reduce=1),
+                dict(render_mode=2, chunk=64, tight_bins=0, exact_cull=0, fast_exp=1),
+                dict(render_mode=2, chunk=256, tight_bins=1, exact_cull=1, fast_exp=1, bwd_reduce=0)]
+    parity(variants[:1] if quick else variants, cases + [dict(P=1500, F=64), dict(P=40000, F=3, W=256, H=256)])
     _lib.set_option("bwd_reduce", 1)
-    for tb in (0, 1):
-        _lib.set_option("tight_bins", tb)
-        sc, cam, kw, dC, dF = util.scene_case(P=100000, F=32)
-        util.run_hip(sc, cam, dC, dF, 1, True, (0.0, 0.0, 0.0))
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(5):
-            util.run_hip(sc, cam, dC, dF, 1, True, (0.0, 0.0, 0.0))
-        torch.cuda.synchronize()
-        print(f"tight={tb}: P=100k F=32 fwd+bwd incl. host overhead+H2D: {(time.time() - t0) / 5 * 1e3:.2f} ms")
+    base = dict(tight_bins=1, fast_exp=0, exact_cull=1)
+    timing([dict(render_mode=0, **base), dict(render_mode=1, chunk=128, **base),
+            dict(render_mode=2, chunk=64, **base), dict(render_mode=2, chunk=128, **base),
+            dict(render_mode=2, chunk=256, **base), dict(render_mode=2, chunk=128, tight_bins=1, fast_exp=1, exact_cull=1),
+            dict(render_mode=2, chunk=128, tight_bins=1, fast_exp=1, exact_cull=0),
+            dict(render_mode=2, chunk=128, tight_bins=0, fast_exp=1, exact_cull=1)])
 
 
 if __name__ == "__main__":

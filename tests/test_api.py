@@ -30,8 +30,8 @@ def test_workspace_size_queries_and_options():
     assert L.mgs_geom_bytes(1000, 4) > 1000 * 75
     assert L.mgs_geom_bytes(2000, 4) > L.mgs_geom_bytes(1000, 4)
     assert L.mgs_img_bytes(128, 128) >= 128 * 128 * 8
-    assert L.mgs_binning_bytes(5000, 128, 128) > 5000 * 24
-    assert L.mgs_binning_bytes(0, 128, 128) > 0
+    assert L.mgs_binning_bytes(5000, 128, 128, 32) > 5000 * 24
+    assert L.mgs_binning_bytes(0, 128, 128, 0) > 0
     old = _lib.get_option("tight_bins")
     _lib.set_option("tight_bins", 1 - old)
     assert _lib.get_option("tight_bins") == 1 - old
