@@ -230,18 +230,33 @@ def test_full_size_properties(P, W):
         assert (gp[k] - g1[k][perm]).abs().max().item() <= GRAD_TOL * g1[k].abs().max().item(), k
 
 
-def test_tight_bins_is_result_preserving_at_full_size():
+@pytest.mark.parametrize("render_mode", [0, 2], ids=["whole_list_walk", "cooperative_chunks"])
+def test_tight_bins_is_result_preserving_at_full_size(render_mode):
+    """Dropping the (Gaussian, tile) instances whose alpha >= 1/255 footprint misses the tile removes only pairs
+    that every pixel of the tile skips: the same pairs are blended in the same order.  With the whole-list walk
+    that is bit-identical; with the chunk-parallel render the chunk boundaries move with the list, so the partial
+    sums are grouped differently and equality holds to float rounding."""
     d, rast, cam = _full()
     dev = d["means3D"].device
     g = torch.Generator().manual_seed(9)
     dC, dF = torch.randn(3, 128, 128, generator=g).to(dev), torch.randn(32, 128, 128, generator=g).to(dev)
-    _lib.set_option("tight_bins", 0)
-    c0, f0, r0, g0 = _fwd_bwd(d, rast, dC, dF)
-    _lib.set_option("tight_bins", 1)
-    c1, f1, r1, g1 = _fwd_bwd(d, rast, dC, dF)
-    assert torch.equal(c0, c1) and torch.equal(f0, f1) and torch.equal(r0, r1)  # same pairs blended, same order
+    old_mode = _lib.get_option("render_mode")
+    try:
+        _lib.set_option("render_mode", render_mode)
+        _lib.set_option("tight_bins", 0)
+        c0, f0, r0, g0 = _fwd_bwd(d, rast, dC, dF)
+        _lib.set_option("tight_bins", 1)
+        c1, f1, r1, g1 = _fwd_bwd(d, rast, dC, dF)
+    finally:
+        _lib.set_option("render_mode", old_mode)
+        _lib.set_option("tight_bins", 1)
+    assert torch.equal(r0, r1)
+    if render_mode == 0:
+        assert torch.equal(c0, c1) and torch.equal(f0, f1)
+    else:
+        assert (c0 - c1).abs().max().item() <= 2e-6 and (f0 - f1).abs().max().item() <= 2e-6
     for k in g0:
-        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * g0[k].abs().max().item() + 1e-9, k
+        assert (g0[k] - g1[k]).abs().max().item() <= 2e-5 * g0[k].abs().max().item() + 1e-9, k
 
 
 def test_sharded_views_on_gpu_equal_sum_of_views():
