@@ -9,7 +9,7 @@ Workload at N=1 = BASELINE.json configs[2] ("100k Gaussians, 128x128, RGB + 32-c
 Gaussians (SURVEY.md 8d statistics), SH degree 1 (M=4), F=32, one look-at view per GPU per step, production
 negative-focal cameras, inputs resident in HBM.  A step = one forward + one backward of the rasterizer
 through the public GaussianRasterizer autograd API (+ one all-reduce of the flat per-Gaussian gradient
-bucket when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
+buffer when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
 
 The JSON line also carries
   roofline:     the dominant kernel (render backward) timed live with HIP events on its launch stream,
@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib  # noqa: E402
 from manigaussian_amd import synthetic as syn  # noqa: E402
-from manigaussian_amd.parallel import GradBucket  # noqa: E402
+from manigaussian_amd.parallel import all_reduce_grads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -102,16 +102,15 @@ def main():
     d_color, d_feat = d_color_h.to(dev), d_feat_h.to(dev)
     settings = GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev))
     rast = GaussianRasterizer(settings)
-    bucket = GradBucket(params)
-    info = {}
+    plist = list(params.values())
 
     def step():
-        bucket.attach()
         color, feat, radii = rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
                                   shs=params["shs"], language_feature_precomp=params["language_feature"],
                                   scales=params["scales"], rotations=params["rotations"])
-        torch.autograd.backward([color, feat], [d_color, d_feat])
-        bucket.all_reduce()
+        grads = torch.autograd.grad([color, feat], plist, [d_color, d_feat])
+        all_reduce_grads(grads)  # N > 1: ONE in-place all-reduce of the allocation all gradients alias
+        return grads
 
     def sync_all():
         torch.cuda.synchronize()
@@ -173,7 +172,7 @@ def main():
                                    f"feature, fwd+bwd, 1 view per GPU per step, negative-focal look-at cameras",
                        "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": 1, "num_rendered_R": int(R),
                        "R_over_P": R / P, "tight_bins": _lib.get_option("tight_bins"),
-                       "collective": "1 all-reduce of the flat per-Gaussian grad bucket" if n_gpus > 1 else "none"},
+                       "collective": "1 in-place all-reduce of the flat per-Gaussian gradient buffer" if n_gpus > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel (K8)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_k8, "avg_launch_ms": bwd_avg_ms, "launches": bwd_n},

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 1
+#define MGS_ABI_VERSION 2
 
 /* error codes */
 #define MGS_OK 0
@@ -42,6 +42,7 @@ extern "C" {
 #define MGS_ERR_HIP (-2)           /* a HIP runtime call or (debug=1) a kernel failed */
 #define MGS_ERR_WORKSPACE (-3)     /* a caller-provided workspace is too small */
 #define MGS_ERR_NON_RGB (-4)       /* reference: "For non-RGB, provide precomputed Gaussian colors!" */
+#define MGS_NEED_CAPACITY 1        /* mgs_rasterize_forward: binning workspace smaller than num_rendered needs */
 
 #define MGS_MAX_FEATURE_CHANNELS 64
 
@@ -74,8 +75,8 @@ typedef struct MgsRasterArgs {
   const float* projmatrix;      /* [16] transposed full projection                                    */
   const float* campos;          /* [3]                                                                */
   /* opaque workspaces, caller-allocated device memory (uint8 tensors in the reference) */
-  void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M)            */
-  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H, F)   */
+  void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M, W, H)      */
+  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H, F); forward and backward must pass the SAME size */
   void* img;     size_t img_bytes;      /* >= mgs_img_bytes(W, H)             */
 } MgsRasterArgs;
 
@@ -88,7 +89,7 @@ int mgs_get_option(const char* key);
 
 /* Workspace sizes.  Replace required<GeometryState/ImageState/BinningState>()
  * (RAST/cuda_rasterizer/rasterizer_impl.h:65-72, rasterizer_impl.cu:155-194). */
-size_t mgs_geom_bytes(int P, int M);
+size_t mgs_geom_bytes(int P, int M, int W, int H);
 size_t mgs_img_bytes(int W, int H);
 size_t mgs_binning_bytes(int R, int W, int H, int F);  /* F = feature channels rendered (0 if none) */
 size_t mgs_backward_scratch_bytes(int P, int M, int F);
@@ -106,6 +107,21 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
  * out_feature [F,H,W] (untouched if !include_feature).  Both are fully written (no pre-zeroing needed). */
 int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
                                  float* out_color, float* out_feature, mgs_stream_t stream);
+
+/* Fused forward: stage 1 + stage 2 in one call with NO mid-call stream synchronisation (the reference
+ * blocks on a cudaMemcpy at rasterizer_impl.cu:284; on MI355X that bubble costs more than the binning).
+ * The binning workspace is sized by the CALLER's guess (e.g. the high-water mark of earlier calls):
+ * a->binning_bytes = mgs_binning_bytes(capacity, W, H, F).  The layout of a binning workspace is a
+ * function of its byte size alone, so the backward needs no capacity argument.
+ *   host_status: 8 bytes of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory), 8-byte
+ *     aligned, owned by the calling thread; the device reports {flags, num_rendered} through it as soon as
+ *     the preprocess has run and the call returns without waiting for the render.  NULL: the call reads
+ *     the count back with a blocking copy instead (same results, slower).
+ * Returns MGS_OK (images written / enqueued, *num_rendered set) or MGS_NEED_CAPACITY (*num_rendered set,
+ * geom + radii valid, images NOT rendered: call mgs_rasterize_forward_render with a binning workspace of
+ * at least mgs_binning_bytes(*num_rendered, W, H, F)). */
+int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_color, float* out_feature,
+                          int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream);
 
 /* Backward (K8-K10).  Replaces Rasterizer::backward (rasterizer_impl.cu:359-463) and the output
  * allocation of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:167-184).  Every non-NULL output

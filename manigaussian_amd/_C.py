@@ -56,6 +56,32 @@ def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefilt
     a.img, a.img_bytes = _ptr(img), 0 if img is None else img.numel()
 
 
+# Per-device host state of the sync-free forward: one pinned 8-byte status word (the device reports
+# {flags, num_rendered} through it) and the high-water mark of num_rendered per problem shape, which sizes
+# the binning workspace BEFORE the count is known (the reference sizes it after a blocking read-back).
+_DEV_STATE = {}
+
+
+def _dev_state(dev):
+    st = _DEV_STATE.get(dev)
+    if st is None:
+        pin = torch.zeros(2, dtype=torch.int64).pin_memory()
+        st = {"status": pin, "status_ptr": pin.data_ptr(), "cap": {}}
+        _DEV_STATE[dev] = st
+    return st
+
+
+def _capacity_guess(st, key, P):
+    cap = st["cap"].get(key)
+    return cap if cap is not None else 4 * P + 4096
+
+
+def _remember_capacity(st, key, R):
+    want = R + R // 4 + 4096  # 25 % head-room over the largest count seen for this shape
+    if st["cap"].get(key, 0) < want:
+        st["cap"][key] = want
+
+
 def rasterize_gaussians(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
                         degree, campos, prefiltered, debug, include_feature):
@@ -94,35 +120,42 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
             language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
 
     with torch.cuda.device(dev):
+        u8 = dict(dtype=torch.uint8, device=dev)
+        if P == 0:  # rasterize_points.cu:92: empty workspaces, zero images
+            out_color = torch.zeros((3, H, W), dtype=_F32, device=dev)
+            out_feat = torch.zeros((F_user, H, W) if include_feature else (1,), dtype=_F32, device=dev)
+            e = torch.empty((0,), **u8)
+            return 0, out_color, out_feat, torch.zeros((0,), dtype=torch.int32, device=dev), e, e.clone(), e.clone()
         out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
         out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
             torch.zeros((1,), dtype=_F32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-        u8 = dict(dtype=torch.uint8, device=dev)
-        if P == 0:  # rasterize_points.cu:92: empty workspaces, zero images
-            out_color.zero_()
-            out_feat.zero_()
-            e = torch.empty((0,), **u8)
-            return 0, out_color, out_feat[:F_user] if include_feature else out_feat, radii, e, e.clone(), e.clone()
-        geom = torch.empty((L.mgs_geom_bytes(P, M),), **u8)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)  # written for every Gaussian by the preprocess
+        st = _dev_state(dev)
+        key = (P, W, H, F)
+        cap = _capacity_guess(st, key, P)
+        geom = torch.empty((L.mgs_geom_bytes(P, M, W, H),), **u8)
         img = torch.empty((L.mgs_img_bytes(W, H),), **u8)
+        binning = torch.empty((L.mgs_binning_bytes(cap, W, H, F),), **u8)
         a = _lib.MgsRasterArgs()
-        kw = dict(P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
-                  scale_modifier=float(scale_modifier), prefiltered=prefiltered, debug=debug,
-                  include_feature=include_feature, background=background, means3D=means3D, sh=sh, colors=colors,
-                  language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
-                  cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos)
-        _fill_args(a, geom=geom, binning=None, img=img, **kw)
+        _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
+                   scale_modifier=float(scale_modifier), prefiltered=prefiltered, debug=debug,
+                   include_feature=include_feature, background=background, means3D=means3D, sh=sh, colors=colors,
+                   language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
+                   cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos,
+                   geom=geom, binning=binning, img=img)
         stream = _stream(dev)
         nr = ctypes.c_int32(0)
-        _lib.check(L.mgs_rasterize_forward_preprocess(ctypes.byref(a), radii.data_ptr(), ctypes.byref(nr), stream),
-                   "rasterize_gaussians (preprocess)")
+        feat_ptr = out_feat.data_ptr() if include_feature else None
+        rc = L.mgs_rasterize_forward(ctypes.byref(a), radii.data_ptr(), out_color.data_ptr(), feat_ptr,
+                                     ctypes.byref(nr), st["status_ptr"], stream)
         R = int(nr.value)
-        binning = torch.empty((L.mgs_binning_bytes(R, W, H, F),), **u8)
-        a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
-        _lib.check(L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(),
-                                                  _ptr(out_feat) if include_feature else None, stream),
-                   "rasterize_gaussians (render)")
+        if rc == _lib.MGS_NEED_CAPACITY:  # first call for this shape, or the scene grew: bin + render again
+            binning = torch.empty((L.mgs_binning_bytes(R + R // 4 + 4096, W, H, F),), **u8)
+            a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
+            rc = L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(), feat_ptr,
+                                                stream)
+        _lib.check(rc, "rasterize_gaussians")
+        _remember_capacity(st, key, R)
     if include_feature and F != F_user:
         out_feat = out_feat[:F_user].contiguous()
     return R, out_color, out_feat, radii, geom, binning, img
@@ -159,35 +192,37 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, language_fe
             dL_dout_language_feature = torch.cat(
                 [dL_dout_language_feature, dL_dout_language_feature.new_zeros((F - F_user, H, W))], 0)
     with torch.cuda.device(dev):
-        opts = dict(dtype=_F32, device=dev)
-        g_means3D = torch.empty((P, 3), **opts)
-        g_means2D = torch.empty((P, 3), **opts)
-        g_colors = torch.empty((P, 3), **opts)
-        g_feat = torch.empty((P, F), **opts) if include_feature else torch.zeros((1,), **opts)
-        g_opacity = torch.empty((P, 1), **opts)
-        g_cov3D = torch.empty((P, 6), **opts)
-        g_sh = torch.empty((P, M, 3), **opts)
-        g_scales = torch.empty((P, 3), **opts)
-        g_rot = torch.empty((P, 4), **opts)
-        if P != 0:
-            scratch = torch.empty((L.mgs_backward_scratch_bytes(P, M, F),), dtype=torch.uint8, device=dev)
-            a = _lib.MgsRasterArgs()
-            _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
-                       scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
-                       include_feature=include_feature, background=_f32c(background, "background", dev),
-                       means3D=means3D, sh=sh, colors=colors, language_feature=language_feature, opacity=None,
-                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
-                       viewmatrix=_f32c(viewmatrix, "viewmatrix", dev), projmatrix=_f32c(projmatrix, "projmatrix", dev),
-                       campos=_f32c(campos, "campos", dev), geom=geomBuffer, binning=binningBuffer, img=imageBuffer)
-            _lib.check(L.mgs_rasterize_backward(
-                ctypes.byref(a), int(R), radii.data_ptr(), dL_dout_color.data_ptr(),
-                _ptr(dL_dout_language_feature) if include_feature else None, g_means2D.data_ptr(), None,
-                g_opacity.data_ptr(), g_colors.data_ptr(), _ptr(g_feat) if include_feature else None,
-                g_means3D.data_ptr(), g_cov3D.data_ptr(), _ptr(g_sh), g_scales.data_ptr(), g_rot.data_ptr(),
-                scratch.data_ptr(), scratch.numel(), _stream(dev)), "rasterize_gaussians_backward")
+        if P == 0:
+            z = lambda *s_: torch.zeros(s_, dtype=_F32, device=dev)  # noqa: E731
+            return (z(0, 3), z(0, 3), z(0, F_user) if include_feature else z(1), z(0, 1), z(0, 3), z(0, 6),
+                    z(0, M, 3), z(0, 3), z(0, 4))
+        # ONE allocation for the scratch accumulators and every gradient: the three regions the render backward
+        # accumulates into (acc8 | dL_dcolors | dL_dfeature) come first and are contiguous, so the library zeroes
+        # them with a single fill; everything else is fully written by the kernels.
+        scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
+        sizes = [scratch_f, 3 * P, F * P, 3 * P, 3 * P, P, 6 * P, 3 * M * P, 3 * P, 4 * P]
+        flat = torch.empty((sum(sizes),), dtype=_F32, device=dev)
+        (scratch, g_colors, g_feat, g_means3D, g_means2D, g_opacity, g_cov3D, g_sh, g_scales,
+         g_rot) = flat.split_with_sizes(sizes)
+        a = _lib.MgsRasterArgs()
+        _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
+                   scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
+                   include_feature=include_feature, background=_f32c(background, "background", dev),
+                   means3D=means3D, sh=sh, colors=colors, language_feature=language_feature, opacity=None,
+                   scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                   viewmatrix=_f32c(viewmatrix, "viewmatrix", dev), projmatrix=_f32c(projmatrix, "projmatrix", dev),
+                   campos=_f32c(campos, "campos", dev), geom=geomBuffer, binning=binningBuffer, img=imageBuffer)
+        _lib.check(L.mgs_rasterize_backward(
+            ctypes.byref(a), int(R), radii.data_ptr(), dL_dout_color.data_ptr(),
+            _ptr(dL_dout_language_feature) if include_feature else None, g_means2D.data_ptr(), None,
+            g_opacity.data_ptr(), g_colors.data_ptr(), _ptr(g_feat) if include_feature else None,
+            g_means3D.data_ptr(), g_cov3D.data_ptr(), _ptr(g_sh), g_scales.data_ptr(), g_rot.data_ptr(),
+            scratch.data_ptr(), scratch.numel() * 4, _stream(dev)), "rasterize_gaussians_backward")
+        g_feat = g_feat.view(P, F) if include_feature else torch.zeros((1,), dtype=_F32, device=dev)
     if include_feature and F != F_user:
         g_feat = g_feat[:, :F_user].contiguous()
-    return g_means2D, g_colors, g_feat, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot
+    return (g_means2D.view(P, 3), g_colors.view(P, 3), g_feat, g_opacity.view(P, 1), g_means3D.view(P, 3),
+            g_cov3D.view(P, 6), g_sh.view(P, M, 3), g_scales.view(P, 3), g_rot.view(P, 4))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

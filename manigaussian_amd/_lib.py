@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -17,6 +17,7 @@ c_sz = ctypes.c_size_t
 
 # error codes (include/mgsplat.h)
 MGS_OK, MGS_ERR_INVALID_ARG, MGS_ERR_HIP, MGS_ERR_WORKSPACE, MGS_ERR_NON_RGB = 0, -1, -2, -3, -4
+MGS_NEED_CAPACITY = 1
 
 SUPPORTED_F = (3, 4, 8, 16, 32, 64)
 
@@ -40,13 +41,15 @@ _EXPORTS = {
     "mgs_last_error": (ctypes.c_char_p, []),
     "mgs_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "mgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
-    "mgs_geom_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "mgs_geom_bytes": (c_sz, [ctypes.c_int] * 4),
     "mgs_img_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
     "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_backward_scratch_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_rasterize_forward_preprocess": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp,
                                                         ctypes.POINTER(c_i32), c_fp]),
     "mgs_rasterize_forward_render": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp, c_fp, c_fp, c_fp]),
+    "mgs_rasterize_forward": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp, c_fp, c_fp, ctypes.POINTER(c_i32),
+                                             c_fp, c_fp]),
     "mgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp] + [c_fp] * 12 +
                                [c_fp, c_sz, c_fp]),
     "mgs_mark_visible": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),

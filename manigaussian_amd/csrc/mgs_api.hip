@@ -36,7 +36,7 @@ static bool supported_F(int F) {
 // ---- per-stage timing with hipEvents on the caller's stream (mgs_set_option("profile", 1|2)) ----
 enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_BWD_MEMSET, ST_RENDER_BWD,
              ST_PREPROCESS_BWD, ST_COUNT };
-static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_with_keys", "radix_sort",
+static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_with_keys", "binning_sort",
                                                   "ranges_gather", "render_fwd", "bwd_memset", "render_bwd",
                                                   "preprocess_bwd"};
 struct Profiler {
@@ -139,6 +139,11 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "render_mode")) o.render_mode = value;
   else if (!strcmp(key, "chunk")) o.chunk = value;
   else if (!strcmp(key, "exact_cull")) o.exact_cull = value;
+  else if (!strcmp(key, "bin_mode")) o.bin_mode = value;
+  else if (!strcmp(key, "seg")) {
+    if (value != 512 && value != 1024 && value != 2048) { set_error("seg must be 512, 1024 or 2048"); return MGS_ERR_INVALID_ARG; }
+    o.seg = value;
+  }
   else { set_error("unknown option %s", key); return MGS_ERR_INVALID_ARG; }
   return MGS_OK;
 }
@@ -151,11 +156,16 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "render_mode")) return o.render_mode;
   if (!strcmp(key, "chunk")) return o.chunk;
   if (!strcmp(key, "exact_cull")) return o.exact_cull;
+  if (!strcmp(key, "bin_mode")) return o.bin_mode;
+  if (!strcmp(key, "seg")) return o.seg;
   set_error("unknown option %s", key);
   return MGS_ERR_INVALID_ARG;
 }
 
-size_t mgs_geom_bytes(int P, int M) { size_t t; carve_geom(nullptr, P, M, &t); return t; }
+static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+// segment-sort binning keeps per-tile tables in LDS; larger tile grids take the legacy rocPRIM path
+static bool segsort_binning(int T) { return options().bin_mode == 1 && T <= LDS_TILES; }
+size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
 static int chunk_size() {  // 0 when the chunk-parallel render is off
   const Options& o = options();
@@ -163,28 +173,42 @@ static int chunk_size() {  // 0 when the chunk-parallel render is off
   int ch = o.chunk < 64 ? 64 : o.chunk;
   return (ch + 63) / 64 * 64;
 }
-static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 size_t mgs_binning_bytes(int R, int W, int H, int F) {
   size_t t;
-  carve_binning(nullptr, R, num_tiles(W, H), F, chunk_size(), nullptr, &t);
+  carve_binning(nullptr, R, num_tiles(W, H), F, chunk_size(), !segsort_binning(num_tiles(W, H)), nullptr, &t);
   return t;
 }
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
 
-int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
-                                     mgs_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_common(a);
-  if (rc) return rc;
-  if (!num_rendered) { set_error("num_rendered is NULL"); return MGS_ERR_INVALID_ARG; }
-  *num_rendered = 0;
-  if (a->P == 0) return MGS_OK;  // rasterize_points.cu:92
+// Largest instance capacity whose binning layout fits `bytes`: the layout of a binning workspace is a function
+// of its SIZE, so forward and backward agree on it whatever count the caller passes.
+static int binning_capacity(size_t bytes, int T, int F, bool legacy) {
+  auto need = [&](int R) { size_t t; carve_binning(nullptr, R, T, F, chunk_size(), legacy, nullptr, &t); return t; };
+  if (need(0) > bytes) return -1;
+  int lo = 0, hi = 1;
+  while (hi < (1 << 30) && need(hi) <= bytes) { lo = hi; hi <<= 1; }
+  while (hi - lo > 1) {
+    const int mid = lo + (hi - lo) / 2;
+    if (need(mid) <= bytes) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+static const uint64_t kStatusPending = ~0ull;
+
+// Everything of the forward before the instance count is known: zero tables, preprocess (+ legacy scan).
+static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_t stream, GeomView& g, ImgView& im,
+                              bool& segsort) {
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
-  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M)) {
-    set_error("geom workspace too small: %zu < %zu", a->geom_bytes, mgs_geom_bytes(a->P, a->M));
+  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img ||
+      a->img_bytes < mgs_img_bytes(a->W, a->H)) {
+    set_error("geom/img workspace too small: %zu < %zu or %zu < %zu", a->geom_bytes,
+              mgs_geom_bytes(a->P, a->M, a->W, a->H), a->img_bytes, mgs_img_bytes(a->W, a->H));
     return MGS_ERR_WORKSPACE;
   }
-  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
+  g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), nullptr);
+  im = carve_img(a->img, a->W, a->H, nullptr);
+  g.flags = im.flags;
   FwdPreArgs p;
   p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
   p.tiles_x = (a->W + TILE - 1) / TILE; p.tiles_y = (a->H + TILE - 1) / TILE;
@@ -196,60 +220,70 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-  MGS_HIP(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream), "memset flags");
+  segsort = segsort_binning(p.tiles_x * p.tiles_y);
+  MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
+  p.tile_hist = segsort ? im.tile_hist : nullptr;
+  p.blk_base = segsort ? g.blk_base : nullptr;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_STAGE(launch_preprocess_fwd(p, g, radii, stream), "preprocess", a->debug, stream); }
-  { StageTimer t(ST_SCAN, stream);
-    MGS_STAGE(launch_scan(g, a->P, stream), "tile-count scan", a->debug, stream); }
-  // the one host read-back of the forward, where the reference has it (rasterizer_impl.cu:284)
-  uint32_t host[2] = {0, 0};
-  MGS_HIP(hipMemcpyAsync(&host[0], g.point_offsets + (a->P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
-          "num_rendered read-back");
-  MGS_HIP(hipMemcpyAsync(&host[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "flag read-back");
-  MGS_HIP(hipStreamSynchronize(stream), "stream sync");
-  if (host[1] & 1u) {
-    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");  // auxiliary.h:158
-    return MGS_ERR_INVALID_ARG;
+  if (!segsort) {
+    StageTimer t(ST_SCAN, stream);
+    MGS_STAGE(launch_scan(g, a->P, stream), "tile-count scan", a->debug, stream);
   }
-  *num_rendered = (int32_t)host[0];
   return MGS_OK;
 }
 
-int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_t* radii, float* out_color,
-                                 float* out_feature, mgs_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_common(a);
-  if (rc) return rc;
-  if (!out_color) { set_error("out_color is NULL"); return MGS_ERR_INVALID_ARG; }
-  const size_t N = (size_t)a->W * a->H;
-  const int F = a->include_feature ? a->F : 0;
-  if (F > 0 && !out_feature) { set_error("out_feature is NULL"); return MGS_ERR_INVALID_ARG; }
-  if (a->P == 0) {  // rasterize_points.cu:70-92: zero-filled outputs, nothing launched
-    MGS_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream), "memset out_color");
-    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, F * N * sizeof(float), stream), "memset out_feature");
-    return MGS_OK;
+// Blocking read-back of {instance count, flags} (the reference's cudaMemcpy, rasterizer_impl.cu:284).
+static int read_count_blocking(const GeomView& g, int P, bool segsort, hipStream_t stream, uint32_t* R, uint32_t* fl) {
+  uint32_t host[2] = {0, 0};
+  MGS_HIP(hipMemcpyAsync(&host[0], segsort ? g.flags + 1 : g.point_offsets + (P - 1), sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, stream), "num_rendered read-back");
+  MGS_HIP(hipMemcpyAsync(&host[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "flag read-back");
+  MGS_HIP(hipStreamSynchronize(stream), "stream sync");
+  *R = host[0]; *fl = host[1];
+  return MGS_OK;
+}
+
+static int check_prefiltered(uint32_t fl) {
+  if (fl & 1u) {
+    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");  // auxiliary.h:158
+    return MGS_ERR_INVALID_ARG;
   }
-  if (R < 0 || !radii) { set_error("num_rendered < 0 or radii NULL"); return MGS_ERR_INVALID_ARG; }
-  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
-      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H, F)) {
-    set_error("workspace too small (geom %zu/%zu, img %zu/%zu, binning %zu/%zu)", a->geom_bytes,
-              mgs_geom_bytes(a->P, a->M), a->img_bytes, mgs_img_bytes(a->W, a->H), a->binning_bytes,
-              mgs_binning_bytes(R, a->W, a->H, F));
+  return MGS_OK;
+}
+
+// Binning + render.  R: instance count if the host knows it (legacy binning needs it), else -1.
+// cap: capacity of the binning workspace; host_status: see mgs_rasterize_forward.
+static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, float* out_color, float* out_feature,
+                          uint64_t* host_status, hipStream_t stream) {
+  const int F = a->include_feature ? a->F : 0;
+  const int T = num_tiles(a->W, a->H);
+  const bool segsort = segsort_binning(T);
+  GeomView g = carve_geom(a->geom, a->P, a->M, T, nullptr);
+  ImgView im = carve_img(a->img, a->W, a->H, nullptr);
+  g.flags = im.flags;
+  const int cap = binning_capacity(a->binning_bytes, T, F, !segsort);
+  if (!a->binning || cap < 0 || (R >= 0 && R > cap)) {
+    set_error("binning workspace too small: %zu bytes hold %d instances, need %d", a->binning_bytes, cap, R);
     return MGS_ERR_WORKSPACE;
   }
-  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
-  ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
   const int CH = chunk_size();
-  BinView b = carve_binning(a->binning, R, num_tiles(a->W, a->H), F, CH, &cv, nullptr);
+  BinView b = carve_binning(a->binning, cap, T, F, CH, !segsort, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
-  { StageTimer t(ST_DUPLICATE, stream);
-    MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, options().tight_bins, stream),
-              "duplicate_with_keys", a->debug, stream); }
-  { StageTimer t(ST_SORT, stream);
-    MGS_STAGE(launch_sort(b, R, tiles_x, tiles_y, stream), "radix sort", a->debug, stream); }
-  { StageTimer t(ST_RANGES, stream);
-    MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
+  if (segsort) {
+    StageTimer t(ST_SORT, stream);
+    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, cap, tiles_x, tiles_y, options().seg, host_status, stream),
+              "segment-sort binning", a->debug, stream);
+  } else {
+    { StageTimer t(ST_DUPLICATE, stream);
+      MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, options().tight_bins, stream),
+                "duplicate_with_keys", a->debug, stream); }
+    { StageTimer t(ST_SORT, stream);
+      MGS_STAGE(launch_sort(b, R, tiles_x, tiles_y, stream), "radix sort", a->debug, stream); }
+    { StageTimer t(ST_RANGES, stream);
+      MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
+  }
   RenderArgs r;
   r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
   r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull;
@@ -268,6 +302,112 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
   return MGS_OK;
 }
 
+static int check_render_args(const MgsRasterArgs* a, float* out_color, float* out_feature, hipStream_t stream,
+                             bool* done) {
+  *done = false;
+  if (!out_color) { set_error("out_color is NULL"); return MGS_ERR_INVALID_ARG; }
+  const size_t N = (size_t)a->W * a->H;
+  const int F = a->include_feature ? a->F : 0;
+  if (F > 0 && !out_feature) { set_error("out_feature is NULL"); return MGS_ERR_INVALID_ARG; }
+  if (a->P == 0) {  // rasterize_points.cu:70-92: zero-filled outputs, nothing launched
+    MGS_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream), "memset out_color");
+    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, F * N * sizeof(float), stream), "memset out_feature");
+    *done = true;
+  }
+  return MGS_OK;
+}
+
+int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
+                                     mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!num_rendered) { set_error("num_rendered is NULL"); return MGS_ERR_INVALID_ARG; }
+  *num_rendered = 0;
+  if (a->P == 0) return MGS_OK;  // rasterize_points.cu:92
+  GeomView g; ImgView im; bool segsort;
+  rc = enqueue_preprocess(a, radii, stream, g, im, segsort);
+  if (rc) return rc;
+  uint32_t R = 0, fl = 0;
+  rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
+  if (rc) return rc;
+  rc = check_prefiltered(fl);
+  if (rc) return rc;
+  *num_rendered = (int32_t)R;
+  return MGS_OK;
+}
+
+int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_t* radii, float* out_color,
+                                 float* out_feature, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  bool done;
+  rc = check_render_args(a, out_color, out_feature, stream, &done);
+  if (rc || done) return rc;
+  if (R < 0 || !radii) { set_error("num_rendered < 0 or radii NULL"); return MGS_ERR_INVALID_ARG; }
+  if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img ||
+      a->img_bytes < mgs_img_bytes(a->W, a->H)) {
+    set_error("geom/img workspace too small");
+    return MGS_ERR_WORKSPACE;
+  }
+  return enqueue_render(a, R, radii, out_color, out_feature, nullptr, stream);
+}
+
+int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_color, float* out_feature,
+                          int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!num_rendered) { set_error("num_rendered is NULL"); return MGS_ERR_INVALID_ARG; }
+  *num_rendered = 0;
+  bool done;
+  rc = check_render_args(a, out_color, out_feature, stream, &done);
+  if (rc || done) return rc;
+  GeomView g; ImgView im; bool segsort;
+  const int F = a->include_feature ? a->F : 0;
+  const int cap = binning_capacity(a->binning_bytes, num_tiles(a->W, a->H), F, !segsort_binning(num_tiles(a->W, a->H)));
+  if (!a->binning || cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  rc = enqueue_preprocess(a, radii, stream, g, im, segsort);
+  if (rc) return rc;
+  uint32_t R = 0, fl = 0;
+  if (!segsort || !host_status || a->debug) {
+    // no device->host status channel: read back (blocking) like the two-call path
+    rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
+    if (rc) return rc;
+    rc = check_prefiltered(fl);
+    if (rc) return rc;
+    *num_rendered = (int32_t)R;
+    if ((int)R > cap) return MGS_NEED_CAPACITY;
+    return enqueue_render(a, (int)R, radii, out_color, out_feature, nullptr, stream);
+  }
+  // sync-free: everything is enqueued; the binning kernel stores {flags, R} to the mapped host word as soon
+  // as the preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
+  volatile uint64_t* hs = host_status;
+  *hs = kStatusPending;
+  rc = enqueue_render(a, -1, radii, out_color, out_feature, host_status, stream);
+  if (rc) return rc;
+  uint64_t st = *hs;
+  for (uint64_t spins = 0; st == kStatusPending; spins++) {
+    if ((spins & 0x3ff) == 0x3ff) {  // every ~1k polls: has the stream died or finished without reporting?
+      hipError_t q = hipStreamQuery(stream);
+      if (q != hipErrorNotReady) {
+        st = *hs;
+        if (st != kStatusPending) break;
+        set_error("forward finished without reporting the instance count: %s", hipGetErrorString(q));
+        return MGS_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+    st = *hs;
+  }
+  R = (uint32_t)st; fl = (uint32_t)(st >> 32);
+  rc = check_prefiltered(fl);
+  if (rc) return rc;
+  *num_rendered = (int32_t)R;
+  return (int)R > cap ? MGS_NEED_CAPACITY : MGS_OK;
+}
+
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* radii, const float* dL_dout_color,
                            const float* dL_dout_feature, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
                            float* dL_dcolors, float* dL_dfeature, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
@@ -284,16 +424,19 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     return MGS_ERR_INVALID_ARG;
   }
   if (!scratch || scratch_bytes < mgs_backward_scratch_bytes(a->P, a->M, F) || !a->geom ||
-      a->geom_bytes < mgs_geom_bytes(a->P, a->M) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
-      !a->binning || a->binning_bytes < mgs_binning_bytes(R, a->W, a->H, F)) {
+      a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img || a->img_bytes < mgs_img_bytes(a->W, a->H) ||
+      !a->binning) {
     set_error("backward: workspace too small");
     return MGS_ERR_WORKSPACE;
   }
-  GeomView g = carve_geom(a->geom, a->P, a->M, nullptr);
+  const bool segsort = segsort_binning(num_tiles(a->W, a->H));
+  const int cap = binning_capacity(a->binning_bytes, num_tiles(a->W, a->H), F, !segsort);
+  if (cap < 0 || R > cap) { set_error("backward: binning workspace holds %d instances, need %d", cap, R); return MGS_ERR_WORKSPACE; }
+  GeomView g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
   const int CH = chunk_size();
-  BinView b = carve_binning(a->binning, R, num_tiles(a->W, a->H), F, CH, &cv, nullptr);
+  BinView b = carve_binning(a->binning, cap, num_tiles(a->W, a->H), F, CH, !segsort, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, a->P, a->M, F, nullptr);
   const size_t P = (size_t)a->P;
   // accumulators the render backward adds into
@@ -301,9 +444,20 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   // (the reference returns it in both cases, rasterize_points.cu:169,224)
   float* dcol = dL_dcolors;
   { StageTimer t(ST_BWD_MEMSET, stream);
-    MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * P * sizeof(float), stream), "memset acc8");
-    MGS_HIP(hipMemsetAsync(dcol, 0, 3 * P * sizeof(float), stream), "memset dL_dcolors");
-    if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature"); }
+    // one fill when the caller laid acc8 | dL_dcolors | dL_dfeature out back to back (manigaussian_amd/_C.py does)
+    char* z0 = reinterpret_cast<char*>(sc.acc8);
+    char* z_end = z0 + 8 * P * sizeof(float);
+    const size_t scratch_total = mgs_backward_scratch_bytes(a->P, a->M, F);
+    const bool adj_col = reinterpret_cast<char*>(dcol) >= z_end && reinterpret_cast<char*>(dcol) <= z0 + scratch_total + 64;
+    const bool adj_feat = F == 0 || reinterpret_cast<char*>(dL_dfeature) == reinterpret_cast<char*>(dcol) + 3 * P * sizeof(float);
+    if (adj_col && adj_feat) {
+      char* end = reinterpret_cast<char*>(dcol) + (3 + (size_t)F) * P * sizeof(float);
+      MGS_HIP(hipMemsetAsync(z0, 0, (size_t)(end - z0), stream), "memset accumulators");
+    } else {
+      MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * P * sizeof(float), stream), "memset acc8");
+      MGS_HIP(hipMemsetAsync(dcol, 0, 3 * P * sizeof(float), stream), "memset dL_dcolors");
+      if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
+    } }
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (R > 0) {
     RenderArgs r;

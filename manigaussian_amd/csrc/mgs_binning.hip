@@ -1,5 +1,17 @@
-// mgs_binning.hip -- tile binning: inclusive scan of tile counts (K3), (tile|depth) key emission (K4),
-// stable radix sort (K5), tile ranges + packed sorted instance records (K6).
+// mgs_binning.hip -- tile binning (K3-K6): from per-Gaussian tile rects to per-tile, depth-ordered instance
+// lists + the packed sorted instance records the render kernels stream.
+//
+// Two implementations of the same result contract (per tile: instances ordered by view-depth bits, ties by
+// Gaussian index -- what the reference's stable radix sort of (tile<<32 | depth) keys yields,
+// RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320):
+//   bin_mode 1 (default)  tile histogram (built by the forward preprocess) -> LDS-aggregated scatter of
+//                         (depth|id) keys into per-tile slices -> bitonic sort of <= SEG-entry segments in LDS
+//                         -> rank merge across a tile's segments + emission.  3 launches, no library calls.
+//                         Keys (depth bits, id) are unique, so the order is deterministic and equals the
+//                         stable sort's order.
+//   bin_mode 0 (legacy)   rocPRIM scan + duplicate + rocPRIM SortPairs + ranges/gather: 20+ launches at R~300k
+//                         (rocPRIM picks a merge sort there).  Kept for A/B and for images with more than
+//                         LDS_TILES tiles.
 //
 // Follows RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320 for WHAT is produced (64-bit keys
 // tile<<32 | depth bits, stable order, per-tile [start,end) ranges).  The scan and the radix sort come
@@ -9,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "mgs_common.h"
+#include "mgs_device.h"
 
 namespace mgs {
 
@@ -139,6 +152,302 @@ hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im,
   if (R <= 0) return hipSuccess;
   hipLaunchKernelGGL(ranges_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, b.point_list, g.means2D,
                      g.conic_opacity, g.cullext, im.ranges, b.inst);
+  return hipGetLastError();
+}
+
+
+// ================================ segment-sort binning (bin_mode 1) ===================================
+//
+// preprocess (mgs_preprocess.hip)  tile_hist[t] = instances of tile t; blk_base[b][t] = offset reserved by
+//                                  preprocess workgroup b inside tile t's slice; flags[1] = R
+// bin_scatter_kernel               key (depth bits << 32 | id) of every instance -> its tile slice (unordered)
+// bin_segsort_kernel<SEG>          a tile's slice of L keys = ceil(L/SEG) equal segments; one workgroup sorts one
+//                                  segment in LDS (bitonic network on 64-bit keys)
+// bin_merge_emit_kernel<SEG>       final position of a key = its index + its lower-bound rank in the tile's other
+//                                  segments (keys are unique); writes point_list and the packed instance records
+
+__device__ __forceinline__ uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+// Exclusive scan of v[0..n) (LDS) in place; *total (LDS) receives the sum.  All threads of the block call it.
+// tmp: LDS scratch of blockDim.x entries.  blockDim.x <= 1024.
+__device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t* total) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int per = (n + nt - 1) / nt;
+  const int b = tid * per, e = min(n, b + per);
+  uint32_t sum = 0;
+  for (int i = b; i < e; i++) sum += v[i];
+  tmp[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < nt; d <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t add = tid >= d ? tmp[tid - d] : 0u;
+    __syncthreads();
+    tmp[tid] += add;
+    __syncthreads();
+  }
+  uint32_t run = tmp[tid] - sum;  // exclusive prefix of this thread's slice
+  if (tid == nt - 1) *total = tmp[tid];
+  for (int i = b; i < e; i++) { const uint32_t x = v[i]; v[i] = run; run += x; }
+  __syncthreads();
+}
+
+// A tile's slice of L keys is cut into ns = ceil(L/seg) equal segments of seglen = ceil(L/ns) keys.
+// seg_desc[s] = {first key of segment s (absolute), its key count, tile slice start, tile slice length}.
+
+// Workgroups [0, nblk) scatter the keys of PRE_BLOCK Gaussians each (the partition the preprocess used);
+// workgroup nblk publishes ranges and the segment table for the next two kernels.
+__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int P, int T, int tiles_x, int nblk, uint32_t seg,
+                                                                uint32_t capacity, const uint32_t* __restrict__ flags,
+                                                                uint64_t* host_status,
+                                                                const uint2* __restrict__ rect,
+                                                                const float* __restrict__ depths,
+                                                                const uint32_t* __restrict__ tile_hist,
+                                                                const uint32_t* __restrict__ blk_base,
+                                                                uint64_t* __restrict__ keys_unsorted,
+                                                                uint2* __restrict__ ranges,
+                                                                uint32_t* __restrict__ seg_base,
+                                                                uint4* __restrict__ seg_desc) {
+  extern __shared__ uint32_t lds_u[];
+  uint32_t* s_start = lds_u;          // [T] exclusive scan of the histogram
+  uint32_t* s_cnt = lds_u + T;        // [T] write cursor of this workgroup inside its reservation
+  uint32_t* s_base = lds_u + 2 * T;   // [T] this workgroup's reserved offset inside the tile slice
+  __shared__ uint32_t tmp[PRE_BLOCK];
+  __shared__ uint32_t total;
+  const int tid = threadIdx.x;
+  const bool tables = (int)blockIdx.x == nblk;
+  const uint32_t R = flags[1];
+  if (tables && tid == 0 && host_status)  // report {flags, R} to the waiting host thread (mapped pinned memory)
+    __hip_atomic_store(host_status, ((uint64_t)flags[0] << 32) | R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (R > capacity) {  // the workspace cannot hold the lists: publish "nothing binned", the caller retries
+    if (tables) {
+      for (int t = tid; t < T; t += blockDim.x) { ranges[t] = make_uint2(0u, 0u); seg_base[t] = 0u; }
+      if (tid == 0) seg_base[T] = 0u;
+    }
+    return;
+  }
+  const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * T;
+  for (int t = tid; t < T; t += blockDim.x) {
+    s_start[t] = tile_hist[t];
+    s_cnt[t] = 0;
+    s_base[t] = tables ? 0u : row[t];  // only entries of tiles this workgroup contributed to are meaningful
+  }
+  __syncthreads();
+  block_exclusive_scan(s_start, T, tmp, &total);
+  if (tables) {
+    for (int t = tid; t < T; t += blockDim.x) {
+      const uint32_t L = tile_hist[t];
+      ranges[t] = make_uint2(s_start[t], s_start[t] + L);
+      s_base[t] = div_up_u(L, seg);
+    }
+    __syncthreads();
+    block_exclusive_scan(s_base, T, tmp, &total);
+    for (int t = tid; t < T; t += blockDim.x) {
+      const uint32_t L = tile_hist[t], ns = div_up_u(L, seg), sb = s_base[t];
+      const uint32_t seglen = ns ? div_up_u(L, ns) : 0u;
+      seg_base[t] = sb;
+      for (uint32_t k = 0; k < ns; k++)
+        seg_desc[sb + k] = make_uint4(s_start[t] + k * seglen, min(seglen, L - k * seglen), s_start[t], L);
+    }
+    if (tid == 0) seg_base[T] = total;
+    return;
+  }
+  const int idx = blockIdx.x * blockDim.x + tid;
+  if (idx >= P) return;
+  const uint2 r = rect[idx];
+  const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16);
+  const int y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+  if (x1 <= x0 || y1 <= y0) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) {
+      const int t = y * tiles_x + x;
+      const uint32_t slot = s_start[t] + s_base[t] + atomicAdd(&s_cnt[t], 1u);
+      keys_unsorted[slot] = key;
+    }
+}
+
+// ---- bitonic sort of one segment: two keys per lane in registers ---------------------------------------
+// Element e of the segment lives in thread e/2, slot e%2.  Compare-exchange distance j: 1 = inside the thread,
+// 2..64 = lane distance j/2 inside the wave (DPP / permlane swaps, no LDS), >= 128 = across waves through LDS.
+template <int D>
+__device__ __forceinline__ void ce_lane(uint64_t& k0, uint64_t& k1, bool up, int lane) {
+  const bool keep_min = ((lane & D) == 0) == up;
+  const uint64_t p0 = lane_xor64<D>(k0, lane), p1 = lane_xor64<D>(k1, lane);
+  k0 = ((k0 < p0) == keep_min) ? k0 : p0;
+  k1 = ((k1 < p1) == keep_min) ? k1 : p1;
+}
+
+template <int SEGN>
+__global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* __restrict__ n_seg,
+                                                                const uint4* __restrict__ seg_desc,
+                                                                const uint64_t* __restrict__ keys_unsorted,
+                                                                uint64_t* __restrict__ keys) {
+  __shared__ uint64_t sk[SEGN];
+  const uint32_t tid = threadIdx.x;
+  const int lane = (int)(tid & 63u);
+  const uint4 d = seg_desc[blockIdx.x];  // surplus workgroups read an unused (in-bounds) entry
+  if (blockIdx.x >= *n_seg) return;
+  const uint32_t cnt = d.y;
+  const size_t base = d.x;
+  uint32_t n = 128;
+  while (n < cnt) n <<= 1;
+  const uint32_t e0 = 2u * tid;
+  uint64_t k0 = e0 < cnt ? keys_unsorted[base + e0] : ~0ull;
+  uint64_t k1 = e0 + 1u < cnt ? keys_unsorted[base + e0 + 1u] : ~0ull;
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    const bool up = (e0 & k) == 0;  // same for both slots (k >= 2)
+    uint32_t j = k >> 1;
+    if (j >= 128) {
+      sk[e0] = k0; sk[e0 + 1] = k1;
+      for (; j >= 128; j >>= 1) {
+        __syncthreads();
+        if (tid < n / 2) {
+          const uint32_t a = ((tid & ~(j - 1u)) << 1) | (tid & (j - 1u));
+          const uint32_t b = a | j;
+          const bool upa = (a & k) == 0;
+          const uint64_t x = sk[a], y = sk[b];
+          if ((x > y) == upa) { sk[a] = y; sk[b] = x; }
+        }
+      }
+      __syncthreads();
+      k0 = sk[e0]; k1 = sk[e0 + 1];
+    }
+    switch (j) {
+      case 64: ce_lane<32>(k0, k1, up, lane); [[fallthrough]];
+      case 32: ce_lane<16>(k0, k1, up, lane); [[fallthrough]];
+      case 16: ce_lane<8>(k0, k1, up, lane); [[fallthrough]];
+      case 8: ce_lane<4>(k0, k1, up, lane); [[fallthrough]];
+      case 4: ce_lane<2>(k0, k1, up, lane); [[fallthrough]];
+      case 2: ce_lane<1>(k0, k1, up, lane); [[fallthrough]];
+      default: break;
+    }
+    {  // j == 1
+      const uint64_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+      k0 = up ? lo : hi;
+      k1 = up ? hi : lo;
+    }
+  }
+  if (e0 < cnt) keys[base + e0] = k0;
+  if (e0 + 1u < cnt) keys[base + e0 + 1u] = k1;
+}
+
+// lower_bound of key in the sorted LDS array a[0..len), len <= SEGN: fixed trip count, branch-free
+template <int SEGN>
+__device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t* a, uint32_t len, uint64_t key) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (uint32_t s = SEGN; s >= 1; s >>= 1) {
+    const uint32_t q = pos + s;
+    const uint64_t v = a[min(q, len) - 1u + (len == 0u ? 1u : 0u)];
+    pos = (q <= len && v < key) ? q : pos;
+  }
+  return pos;
+}
+
+// Rank of every key of this segment among the tile's other segments, staged through LDS in groups of whole
+// segments (<= CAP keys); then emission.  Two keys per thread.
+template <int SEGN>
+__global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
+                                                                   const uint4* __restrict__ seg_desc,
+                                                                   const uint64_t* __restrict__ keys,
+                                                                   const float2* __restrict__ means2D,
+                                                                   const float4* __restrict__ conic_opacity,
+                                                                   const float2* __restrict__ cullext,
+                                                                   uint32_t* __restrict__ point_list,
+                                                                   float4* __restrict__ inst) {
+  constexpr uint32_t NT = SEGN / 2;
+  constexpr uint32_t CAP = 8192;  // keys staged per group (64 KB)
+  __shared__ uint64_t sk[CAP];
+  const uint32_t tid = threadIdx.x;
+  const uint4 d = seg_desc[blockIdx.x];
+  if (blockIdx.x >= *n_seg) return;
+  const uint32_t cnt = d.y, start = d.z, L = d.w;
+  const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);
+  const uint32_t self = (d.x - start) / seglen;
+  const uint64_t* __restrict__ tk = keys + start;  // the tile's slice
+  uint64_t key[2];
+  uint32_t rank[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const uint32_t i = tid + e * NT;
+    key[e] = i < cnt ? keys[(size_t)d.x + i] : ~0ull;
+    rank[e] = i;
+  }
+  // the per-Gaussian record only depends on the id: fetch it now so the gather overlaps the ranking
+  float2 xy[2], h[2];
+  float4 co[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const uint32_t id = (tid + e * NT) < cnt ? (uint32_t)key[e] : 0u;
+    xy[e] = means2D[id];
+    co[e] = conic_opacity[id];
+    h[e] = cullext[id];
+  }
+  if (ns > 1) {
+    const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
+    for (uint32_t s0 = 0; s0 < ns; s0 += per_group) {
+      const uint32_t s1 = min(ns, s0 + per_group);
+      if (s1 - s0 == 1 && s0 == self) continue;  // the group holds only this workgroup's own segment
+      const uint32_t k0 = s0 * seglen, nk = min(L, s1 * seglen) - k0;
+      __syncthreads();
+      for (uint32_t i0 = 0; i0 < nk; i0 += NT * 8) {  // 8 loads in flight per thread
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const uint32_t i = i0 + u * NT + tid;
+          v[u] = i < nk ? tk[k0 + i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const uint32_t i = i0 + u * NT + tid;
+          if (i < nk) sk[i] = v[u];
+        }
+      }
+      __syncthreads();
+      for (uint32_t s2 = s0; s2 < s1; s2++) {
+        if (s2 == self) continue;
+        const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
+        const uint32_t r0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
+        const uint32_t r1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
+        rank[0] += r0;
+        rank[1] += r1;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const uint32_t i = tid + e * NT;
+    if (i >= cnt) continue;
+    const size_t out = (size_t)start + rank[e];
+    point_list[out] = (uint32_t)key[e];
+    inst[2 * out] = make_float4(xy[e].x, xy[e].y, co[e].x, co[e].y);
+    inst[2 * out + 1] = make_float4(co[e].z, co[e].w, h[e].x, h[e].y);
+  }
+}
+
+template <int SEGN>
+static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
+  const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
+  hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
+                     b.keys_unsorted, b.keys);
+  hipLaunchKernelGGL(bin_merge_emit_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
+                     b.keys, g.means2D, g.conic_opacity, g.cullext, b.point_list, b.inst);
+}
+
+hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int P, int capacity, int tiles_x,
+                              int tiles_y, int seg, uint64_t* host_status, hipStream_t s) {
+  const int R = capacity;  // sizes the segment grids (upper bound)
+  if (P <= 0) return hipSuccess;
+  const int T = tiles_x * tiles_y;
+  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, P, T,
+                     tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
+                     im.ranges, im.seg_base, b.seg_desc);
+  switch (seg) {
+    case 512: launch_sort_merge<512>(g, b, im, R, T, s); break;
+    case 1024: launch_sort_merge<1024>(g, b, im, R, T, s); break;
+    default: launch_sort_merge<2048>(g, b, im, R, T, s); break;
+  }
   return hipGetLastError();
 }
 

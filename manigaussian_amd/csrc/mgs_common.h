@@ -12,6 +12,8 @@ constexpr int TILE = 16;         // tile membership granularity: must stay 16 (R
 constexpr int SUB = 8;           // execution granularity: one wave64 per 8x8 pixel block
 constexpr int SUBS_PER_TILE = 4;
 constexpr int WAVE = 64;
+constexpr int PRE_BLOCK = 1024;   // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
+constexpr int LDS_TILES = 4096;   // max tiles whose per-tile tables fit the binning kernels' LDS (else: legacy rocPRIM binning)
 
 // ---- workspace carving (replaces obtain()/fromChunk, RAST rasterizer_impl.h:19-63) -------------
 constexpr size_t ALIGN = 256;
@@ -40,26 +42,38 @@ struct GeomView {
   float* rgb;               // [3P]  SH -> RGB (unused with colors_precomp)
   float* cov3D;             // [6P]
   uint8_t* clamped;         // [P]   bit c set: SH colour channel c was clamped at 0
-  uint32_t* tiles_touched;  // [P]
-  uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched
-  uint32_t* flags;          // [4]   [0]: prefiltered violation
+  uint2* rect;              // [P]   tile rect the Gaussian is binned into: {x0 | x1<<16, y0 | y1<<16} (x1,y1 exclusive)
+  uint32_t* tiles_touched;  // [P]   (legacy binning only)
+  uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched (legacy binning only)
+  uint32_t* flags;          // [4]   [0]: prefiltered violation, [1]: number of instances (bin_mode 1)
+  uint32_t* blk_base;       // [ceil(P/PRE_BLOCK)][T]  offset of preprocess workgroup b's instances inside tile t's slice
   void* scan_temp;
   size_t scan_temp_bytes;
 };
 
 struct ImgView {
-  float* final_T;       // [N]
-  uint32_t* n_contrib;  // [N]  1-based position in the tile list of the last blended entry
-  uint2* ranges;        // [T]
+  float* final_T;         // [N]
+  uint32_t* n_contrib;    // [N]  1-based position in the tile list of the last blended entry
+  uint2* ranges;          // [T]
+  // tile-binning state (mgs_binning.hip); flags .. seg_base are one contiguous block zeroed per forward
+  uint32_t* flags;        // [4]    [0]: prefiltered violation, [1]: number of instances (bin_mode 1)
+  uint32_t* tile_hist;    // [T]    instances per tile (filled by the forward preprocess)
+  uint32_t* tile_cursor;  // [T]    (unused)
+  uint32_t* seg_base;     // [T+1]  exclusive scan of the tiles' segment counts
+  size_t zero_bytes;      // bytes from flags to the end of seg_base
 };
 
+// Segment-sort binning (bin_mode 1): a tile's instance list of L entries is cut into ceil(L/SEG) equal segments.
+constexpr int SEG_MIN = 512;    // smallest selectable segment size (sizes the segment table)
+
 struct BinView {
-  uint64_t* keys_unsorted;  // [R]
-  uint64_t* keys;           // [R]
-  uint32_t* vals_unsorted;  // [R]
+  uint64_t* keys_unsorted;  // [R]  (depth bits << 32 | id), tile-major, unordered inside a tile  (legacy: tile<<32|depth)
+  uint64_t* keys;           // [R]  segment-sorted keys                                            (legacy: sorted keys)
+  uint32_t* vals_unsorted;  // [R]  legacy only
   uint32_t* point_list;     // [R]  sorted Gaussian ids
   float4* inst;             // [2R] sorted packed records {x,y,cx,cy}{cz,opacity,hx,hy}
-  void* sort_temp;
+  uint4* seg_desc;          // [R/SEG_MIN + T + 2]  segment -> {first key, count, tile slice start, tile slice length}
+  void* sort_temp;          // legacy only
   size_t sort_temp_bytes;
 };
 
@@ -79,7 +93,7 @@ struct ChunkView {
 size_t scan_temp_bytes(int P);
 size_t sort_temp_bytes(int R);
 
-inline GeomView carve_geom(void* p, int P, int M, size_t* total) {
+inline GeomView carve_geom(void* p, int P, int M, int T, size_t* total) {
   Carver c(p);
   GeomView g;
   size_t Pa = P > 0 ? (size_t)P : 1;
@@ -87,12 +101,14 @@ inline GeomView carve_geom(void* p, int P, int M, size_t* total) {
   g.means2D = c.take<float2>(Pa);
   g.conic_opacity = c.take<float4>(Pa);
   g.cullext = c.take<float2>(Pa);
+  g.rect = c.take<uint2>(Pa);
   g.rgb = c.take<float>(3 * Pa);
   g.cov3D = c.take<float>(6 * Pa);
   g.clamped = c.take<uint8_t>(Pa);
   g.tiles_touched = c.take<uint32_t>(Pa);
   g.point_offsets = c.take<uint32_t>(Pa);
   g.flags = c.take<uint32_t>(4);
+  g.blk_base = c.take<uint32_t>(((Pa + PRE_BLOCK - 1) / PRE_BLOCK) * (size_t)(T > 0 && T <= LDS_TILES ? T : 0) + 1);
   g.scan_temp_bytes = scan_temp_bytes((int)Pa);
   g.scan_temp = c.take<char>(g.scan_temp_bytes);
   (void)M;
@@ -108,11 +124,16 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.final_T = c.take<float>(N ? N : 1);
   v.n_contrib = c.take<uint32_t>(N ? N : 1);
   v.ranges = c.take<uint2>(T ? T : 1);
+  v.flags = c.take<uint32_t>(4 + 3 * (T ? T : 1) + 1);  // flags | hist | cursor | seg_base, contiguous
+  v.tile_hist = v.flags ? v.flags + 4 : nullptr;
+  v.tile_cursor = v.flags ? v.tile_hist + (T ? T : 1) : nullptr;
+  v.seg_base = v.flags ? v.tile_hist + 2 * (T ? T : 1) : nullptr;
+  v.zero_bytes = (4 + 3 * (T ? T : 1) + 1) * sizeof(uint32_t);
   if (total) *total = c.total();
   return v;
 }
 
-inline BinView carve_binning(void* p, int R, int T, int F, int CH, ChunkView* cv, size_t* total) {
+inline BinView carve_binning(void* p, int R, int T, int F, int CH, bool legacy, ChunkView* cv, size_t* total) {
   Carver c(p);
   BinView b;
   size_t Ra = R > 0 ? (size_t)R : 1;
@@ -121,7 +142,8 @@ inline BinView carve_binning(void* p, int R, int T, int F, int CH, ChunkView* cv
   b.vals_unsorted = c.take<uint32_t>(Ra);
   b.point_list = c.take<uint32_t>(Ra);
   b.inst = c.take<float4>(2 * Ra);
-  b.sort_temp_bytes = sort_temp_bytes((int)Ra);
+  b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)T + 2);
+  b.sort_temp_bytes = legacy ? sort_temp_bytes((int)Ra) : 0;
   b.sort_temp = c.take<char>(b.sort_temp_bytes);
   if (CH > 0) {  // chunk-parallel render state
     ChunkView v;
@@ -165,6 +187,8 @@ struct Options {
   int render_mode = 2;     // 0: one wave per 8x8 block walks the whole tile list, 1: chunk items, 2: cooperative
   int chunk = 64;          // entries per chunk (multiple of 64) for render_mode 1 and 2
   int exact_cull = 1;      // render_mode 2: exact ellipse-vs-block cull on top of the bbox cull
+  int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: legacy rocPRIM scan + radix sort
+  int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
 };
 Options& options();
 
@@ -173,6 +197,8 @@ void set_error(const char* fmt, ...);
 
 struct FwdPreArgs {
   int P, D, M, W, H, tiles_x, tiles_y;
+  uint32_t* tile_hist;  // [T] instance histogram (zeroed by the caller), or nullptr (legacy binning)
+  uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int prefiltered, tight_bins;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
@@ -180,6 +206,9 @@ struct FwdPreArgs {
 };
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s);
 hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
+// bin_mode 1: scatter -> segment sort -> rank merge + emit (hist is the host copy of im.tile_hist)
+hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int P, int capacity, int tiles_x,
+                              int tiles_y, int seg, uint64_t* host_status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
                             int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);
 hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s);

@@ -94,6 +94,31 @@ __device__ __forceinline__ void bfly_reduce(float* a, int lane) {
   }
 }
 
+// Value of lane (l ^ D) for D in {1,2,4,8,16,32}: DPP within a row, permlane swaps across rows.
+constexpr int DPP_QUAD_REVERSE = 0x1B;  // quad_perm:[3,2,1,0]
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+  const int iv = (int)v;
+  if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, iv, DPP_QUAD_XOR1, 0xf, 0xf, false);
+  else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, iv, DPP_QUAD_XOR2, 0xf, 0xf, false);
+  else if constexpr (D == 4) {  // l^4 = quad-reverse of the half-mirror (7 - l)
+    const int t = __builtin_amdgcn_update_dpp(0, iv, DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, DPP_QUAD_REVERSE, 0xf, 0xf, false);
+  } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, iv, DPP_ROW_ROR8, 0xf, 0xf, false);
+  else if constexpr (D == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    return (uint32_t)(((lane >> 4) & 1) ? r[0] : r[1]);
+  } else {
+    auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+    return (uint32_t)((lane & 32) ? r[0] : r[1]);
+  }
+}
+template <int D>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
+  const uint32_t lo = lane_xor<D>((uint32_t)v, lane), hi = lane_xor<D>((uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 constexpr int next_pow2(int n) { int p = 1; while (p < n) p *= 2; return p; }
 

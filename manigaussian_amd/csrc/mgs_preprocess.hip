@@ -103,11 +103,24 @@ __device__ __forceinline__ void tight_rect(float px, float py, float hx, float h
   y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
 }
 
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdPreArgs a, GeomView g, int32_t* __restrict__ radii) {
+// HIST: also build the per-tile instance histogram (LDS histogram per workgroup, one global atomic per
+// non-empty (workgroup, tile)); the segment-sort binning sizes everything from it.
+template <bool HIST>
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
+                                                                   int32_t* __restrict__ radii) {
+  extern __shared__ uint32_t s_hist[];  // [tiles_x * tiles_y] when HIST
+  __shared__ uint32_t s_total;
+  if (HIST && threadIdx.x == 0) s_total = 0;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.P) return;
+  const int T = a.tiles_x * a.tiles_y;
+  if constexpr (HIST) {
+    for (int t = threadIdx.x; t < T; t += blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+  }
   int32_t radius_out = 0;
   uint32_t touched = 0;
+  int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
+  if (idx < a.P) {
   const float* __restrict__ vm = a.viewmatrix;
   const float* __restrict__ pm = a.projmatrix;
   const V3 p = ld3(a.means3D, idx);
@@ -208,16 +221,38 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdPreArgs a, GeomV
         g.cullext[idx] = make_float2(hx, hy);
         radius_out = (int32_t)my_radius;
         touched = (uint32_t)((y1 - y0) * (x1 - x0));
+        rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;
       }
     }
   }
   radii[idx] = radius_out;
   g.tiles_touched[idx] = touched;
+  if (touched == 0) { rx0 = ry0 = rx1 = ry1 = 0; }
+  g.rect[idx] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
+  }  // idx < P
+  if constexpr (HIST) {
+    for (int y = ry0; y < ry1; y++)
+      for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
+    if (touched) atomicAdd(&s_total, touched);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[1], s_total);
+    // reserve this workgroup's slots inside every tile slice it contributes to; the bin scatter (same
+    // PRE_BLOCK partition of the Gaussians) reads the offsets back
+    uint32_t* __restrict__ row = a.blk_base + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const uint32_t c = s_hist[t];
+      if (c) row[t] = atomicAdd(&a.tile_hist[t], c);
+    }
+  }
 }
 
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, g, radii);
+  if (a.tile_hist)
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((a.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK),
+                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y, s, a, g, radii);
+  else
+    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();
 }
 

@@ -390,6 +390,15 @@ __global__ void selftest_kernel(int* result) {
   if (bcast_lane((float)lane, 37) != 37.f) bad |= 2048;
   if (wave_sum_shfl((float)lane) != 2016.f) bad |= 4096;
   if (wave_umax((uint32_t)lane * 3u) != 189u) bad |= 8192;
+  {
+    const uint32_t v = (uint32_t)lane * 2654435761u;
+    if (lane_xor<1>(v, lane) != (uint32_t)(lane ^ 1) * 2654435761u) bad |= 1 << 14;
+    if (lane_xor<2>(v, lane) != (uint32_t)(lane ^ 2) * 2654435761u) bad |= 1 << 15;
+    if (lane_xor<4>(v, lane) != (uint32_t)(lane ^ 4) * 2654435761u) bad |= 1 << 16;
+    if (lane_xor<8>(v, lane) != (uint32_t)(lane ^ 8) * 2654435761u) bad |= 1 << 17;
+    if (lane_xor<16>(v, lane) != (uint32_t)(lane ^ 16) * 2654435761u) bad |= 1 << 18;
+    if (lane_xor<32>(v, lane) != (uint32_t)(lane ^ 32) * 2654435761u) bad |= 1 << 19;
+  }
   if (bad) atomicOr(result, bad);
 }
 

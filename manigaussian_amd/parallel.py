@@ -63,3 +63,40 @@ def render_sharded(params: Dict[str, torch.Tensor], items: Sequence, render_item
         losses.append(loss.detach())
     handle = bucket.all_reduce(group)
     return losses, handle
+
+
+def flat_alias(grads: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """If every tensor in `grads` is a dense view into ONE storage (the HIP backward hands all gradients out
+    of a single allocation, manigaussian_amd/_C.py), return a 1-D tensor aliasing the span they cover so
+    that one collective reaches all of them in place; else None."""
+    gs = [g for g in grads if g is not None and g.numel() > 0]
+    if not gs:
+        return None
+    st = gs[0].untyped_storage()
+    base_ptr = st.data_ptr()
+    lo, hi = None, None
+    for g in gs:
+        if g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base_ptr:
+            return None
+        b = g.storage_offset()
+        lo = b if lo is None else min(lo, b)
+        hi = b + g.numel() if hi is None else max(hi, b + g.numel())
+    return torch.empty(0, dtype=torch.float32, device=gs[0].device).set_(st, lo, (hi - lo,), (1,))
+
+
+def all_reduce_grads(grads: Sequence[torch.Tensor], group=None, async_op: bool = False):
+    """ONE sum all-reduce over the gradients of a step.  In place on the shared allocation when the gradients
+    alias one buffer (no staging copy); otherwise through a flat staging bucket that is scattered back."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None
+    flat = flat_alias(grads)
+    if flat is not None:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    gs = [g for g in grads if g is not None]
+    bucket = torch.cat([g.reshape(-1) for g in gs])
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in gs:
+        g.copy_(bucket[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return None

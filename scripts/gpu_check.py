@@ -72,8 +72,16 @@ def timing(variants, P=100000, F=32, W=128, steps=30):
               f" | sum={sum(st.values()):.0f}us")
 
 
+def _parse_variants(args):
+    """'a=1,b=2 a=3' -> [{a:1,b:2},{a:3}]"""
+    out = []
+    for a in args:
+        out.append({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.split(",") if kv})
+    return out
+
+
 def main():
-    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    """gpu_check.py [quick] | parity <variants...> | timing <variants...>   (variant = k=v,k=v)"""
     L = _lib.lib()
     print("device:", torch.cuda.get_device_name(0))
     rc = L.mgs_selftest(None)
@@ -81,10 +89,19 @@ def main():
     cases = [dict(P=3000, F=3), dict(P=3000, F=32), dict(P=3000, F=3, neg=False, colors_precomp=True),
              dict(P=20000, F=32), dict(P=2000, F=5), dict(P=2000, F=3, include_feature=False),
              dict(P=3000, F=3, cov3d=True, W=72, H=40), dict(P=30000, F=32, W=64, H=64)]
+    big = [dict(P=1500, F=64), dict(P=40000, F=3, W=256, H=256)]
+    if len(sys.argv) > 2 and sys.argv[1] in ("parity", "timing"):
+        vs = _parse_variants(sys.argv[2:])
+        if sys.argv[1] == "parity":
+            parity(vs, cases + big)
+        else:
+            timing(vs)
+        return
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     variants = [dict(render_mode=2, chunk=128, tight_bins=1, exact_cull=1, fast_exp=0, bwd_reduce=1),
                 dict(render_mode=2, chunk=64, tight_bins=0, exact_cull=0, fast_exp=1),
                 dict(render_mode=2, chunk=256, tight_bins=1, exact_cull=1, fast_exp=1, bwd_reduce=0)]
-    parity(variants[:1] if quick else variants, cases + [dict(P=1500, F=64), dict(P=40000, F=3, W=256, H=256)])
+    parity(variants[:1] if quick else variants, cases + big)
     _lib.set_option("bwd_reduce", 1)
     base = dict(tight_bins=1, fast_exp=0, exact_cull=1)
     timing([dict(render_mode=0, **base), dict(render_mode=1, chunk=128, **base),

@@ -83,3 +83,33 @@ def test_two_rank_all_reduce_equals_single_process_sum(tmp_path):
         ref = p.grad
         assert torch.allclose(got[k], ref, rtol=1e-5, atol=1e-6 * (ref.abs().max().item() + 1e-12)), k
         assert p.grad.data_ptr() == bucket.views[k].data_ptr()  # gradients alias the single flat bucket
+
+
+def _worker_alias(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from manigaussian_amd.parallel import all_reduce_grads, flat_alias
+    flat = torch.arange(20, dtype=torch.float32) * (rank + 1)
+    pad, a, b = flat.split_with_sizes([4, 6, 10])          # the shape the HIP backward hands out: views of one buffer
+    assert flat_alias([a.view(2, 3), b.view(5, 2)]).data_ptr() == a.data_ptr()
+    all_reduce_grads([a.view(2, 3), b.view(5, 2)])        # in place on the shared storage
+    c, d = torch.ones(3) * (rank + 1), torch.ones(2, 2) * (rank + 1)
+    assert flat_alias([c, d]) is None
+    all_reduce_grads([c, d])                               # staging-bucket path
+    if rank == 0:
+        torch.save({"flat": flat, "c": c, "d": d}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_all_reduce_grads_aliasing_and_staging(tmp_path):
+    out = str(tmp_path / "ar.pt")
+    mp.start_processes(_worker_alias, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out)
+    base = torch.arange(20, dtype=torch.float32)
+    expect = base * 3.0
+    expect[:4] = base[:4]                                  # the leading scratch region is outside the reduced span
+    assert torch.equal(got["flat"], expect)
+    assert torch.equal(got["c"], torch.full((3,), 3.0)) and torch.equal(got["d"], torch.full((2, 2), 3.0))
