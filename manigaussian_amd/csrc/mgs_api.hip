@@ -140,6 +140,8 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "chunk")) o.chunk = value;
   else if (!strcmp(key, "exact_cull")) o.exact_cull = value;
   else if (!strcmp(key, "bin_mode")) o.bin_mode = value;
+  else if (!strcmp(key, "bwd_mode")) o.bwd_mode = value;
+  else if (!strcmp(key, "gm_waves")) o.gm_waves = value;
   else if (!strcmp(key, "seg")) {
     if (value != 512 && value != 1024 && value != 2048) { set_error("seg must be 512, 1024 or 2048"); return MGS_ERR_INVALID_ARG; }
     o.seg = value;
@@ -157,6 +159,8 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "chunk")) return o.chunk;
   if (!strcmp(key, "exact_cull")) return o.exact_cull;
   if (!strcmp(key, "bin_mode")) return o.bin_mode;
+  if (!strcmp(key, "bwd_mode")) return o.bwd_mode;
+  if (!strcmp(key, "gm_waves")) return o.gm_waves;
   if (!strcmp(key, "seg")) return o.seg;
   set_error("unknown option %s", key);
   return MGS_ERR_INVALID_ARG;
@@ -467,7 +471,10 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;
     StageTimer t(ST_RENDER_BWD, stream);
-    if (CH > 0 && options().render_mode == 2)
+    if (CH == 64 && options().render_mode == 2 && options().bwd_mode == 1)
+      MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
+                "render backward (gaussian-major)", a->debug, stream);
+    else if (CH > 0 && options().render_mode == 2)
       MGS_STAGE(launch_render_bwd_coop(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
                                        stream), "render backward (coop)", a->debug, stream);
     else if (CH > 0)

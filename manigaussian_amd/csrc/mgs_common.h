@@ -187,6 +187,8 @@ struct Options {
   int render_mode = 2;     // 0: one wave per 8x8 block walks the whole tile list, 1: chunk items, 2: cooperative
   int chunk = 64;          // entries per chunk (multiple of 64) for render_mode 1 and 2
   int exact_cull = 1;      // render_mode 2: exact ellipse-vs-block cull on top of the bbox cull
+  int bwd_mode = 1;        // render_mode 2, chunk 64: 1 = Gaussian-major backward (scans + fp32 MFMA), 0 = pixel-major + butterfly
+  int gm_waves = 16;       // waves per workgroup of the Gaussian-major backward (8 or 16)
   int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: legacy rocPRIM scan + radix sort
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
 };
@@ -239,6 +241,10 @@ hipError_t launch_render_fwd_coop(const RenderArgs& r, const BinView& b, const I
 hipError_t launch_render_bwd_coop(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
                                   const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
                                   float* dL_dfeat, hipStream_t s);
+
+hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
+                                float* dL_dfeat, hipStream_t s);
 
 struct BwdPreArgs {
   int P, D, M, W, H;

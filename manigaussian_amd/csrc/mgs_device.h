@@ -119,6 +119,42 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// ---- scans over each 32-lane half of the wave (lanes 0..31 and 32..63 independently) -----------------
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of every row -> all lanes of the next row (use row_mask 0xA)
+
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float dpp_keep(float old, float v) {  // lanes without a source keep `old`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+// inclusive prefix sum over the lanes of each 32-lane half
+__device__ __forceinline__ float half_incl_scan_add(float v) {
+  v += dpp_keep<DPP_ROW_SHR1>(0.f, v);
+  v += dpp_keep<DPP_ROW_SHR2>(0.f, v);
+  v += dpp_keep<DPP_ROW_SHR4>(0.f, v);
+  v += dpp_keep<DPP_ROW_SHR8>(0.f, v);
+  v += dpp_keep<DPP_ROW_BCAST15, 0xA>(0.f, v);
+  return v;
+}
+// exclusive prefix product over the lanes of each 32-lane half (lane 0 / 32 get 1)
+__device__ __forceinline__ float half_excl_scan_mul(float v, int lane) {
+  float s = dpp_keep<DPP_ROW_SHR1>(1.f, v);                       // lane i <- v[i-1] inside a row
+  const float prev_row_last = dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, v);  // rows 1,3 <- v[15], v[47]
+  s = ((lane & 15) == 0 && (lane & 16)) ? prev_row_last : s;
+  s *= dpp_keep<DPP_ROW_SHR1>(1.f, s);
+  s *= dpp_keep<DPP_ROW_SHR2>(1.f, s);
+  s *= dpp_keep<DPP_ROW_SHR4>(1.f, s);
+  s *= dpp_keep<DPP_ROW_SHR8>(1.f, s);
+  s *= dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, s);
+  return s;
+}
+// value of lane 31 (lanes 0..31) / lane 63 (lanes 32..63)
+__device__ __forceinline__ float half_last(float v, int lane) {
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return (lane & 32) ? b : a;
+}
+
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 constexpr int next_pow2(int n) { int p = 1; while (p < n) p *= 2; return p; }
 

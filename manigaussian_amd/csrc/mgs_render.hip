@@ -399,6 +399,18 @@ __global__ void selftest_kernel(int* result) {
     if (lane_xor<16>(v, lane) != (uint32_t)(lane ^ 16) * 2654435761u) bad |= 1 << 18;
     if (lane_xor<32>(v, lane) != (uint32_t)(lane ^ 32) * 2654435761u) bad |= 1 << 19;
   }
+  {  // half-wave scans (small integers: exact in float)
+    const int n = lane & 31;
+    const float a = (float)((lane * 5) % 7 + 1);
+    float ea = 0.f;
+    for (int i = 0; i <= n; i++) ea += (float)((((lane & 32) + i) * 5) % 7 + 1);
+    if (half_incl_scan_add(a) != ea) bad |= 1 << 20;
+    const float m = (lane % 3 == 0) ? 2.f : 1.f;
+    float em = 1.f;
+    for (int i = 0; i < n; i++) em *= (((lane & 32) + i) % 3 == 0) ? 2.f : 1.f;
+    if (half_excl_scan_mul(m, lane) != em) bad |= 1 << 21;
+    if (half_last((float)lane, lane) != ((lane & 32) ? 63.f : 31.f)) bad |= 1 << 22;
+  }
   if (bad) atomicOr(result, bad);
 }
 

@@ -1,0 +1,371 @@
+// mgs_render_bwd_gm.hip -- Gaussian-major render backward (K8) for the cooperative chunk-parallel forward, gfx950.
+//
+// Results: the reference's renderCUDA backward (RAST/cuda_rasterizer/backward.cu:399-593): for every blended
+// (pixel, Gaussian) pair  dL/dalpha = (D - accum_rec.dL) * T_before - T_final/(1-alpha) * (bg.dL_rgb)  with
+// D = colour/feature row . dL_dpixel, then the chain to mean2D (NDC units), conic, opacity, colour and feature
+// rows, summed over the pixels.  Which pairs are blended comes from the forward (last_pos, T_end per chunk).
+//
+// Decomposition.  mgs_render_coop.hip's backward keeps lane = pixel and, per Gaussian, reduces 9+F values over
+// the 64 pixel lanes with a butterfly: measured VALU-bound (8000 VALU instr. per wave, half of them reduction).
+// Here the roles flip inside a chunk:
+//   lane (n, h) = Gaussian n (0..31) of a group of <= 32 block-reaching entries of the chunk, h = pixel half;
+//   the lane walks its 32 pixels p(u, r, h) = 32u + (r&3) + 8(r>>2) + 4h serially, so every per-Gaussian sum
+//   (mean2D, conic, opacity, colour) is a private register accumulation -- no cross-lane reduction at all;
+//   per pixel, transmittance is an exclusive prefix PRODUCT of (1-alpha) over the group's lanes and the
+//   "colour behind" term an exclusive suffix SUM of D*alpha*T  (DPP row_shr / row_bcast15 scans over each
+//   32-lane half):  accum_rec.dL = S/T_after  =>  dL/dalpha = D*T - (S + T_final*bg.dL)/(1-alpha);
+//   the two dense contractions over channels run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32,
+//   bit-for-bit an fmaf chain): D[pixel][Gaussian] = dL[pixel][ch] . row[Gaussian][ch]  (K = channels), and
+//   dL_dfeature[ch][Gaussian] += dL[pixel][ch] * (alpha*T)[pixel][Gaussian]  (K = pixels).  The pixel order
+//   p(u, r, h) IS the MFMA C-layout (col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)), so D lands in the lane
+//   that needs it and alpha*T is consumed from the lane that made it: no LDS transposes.
+// One atomic per value per group leaves each lane (the pixel lanes of the old kernel needed 64x the adds
+// before their butterfly).  Chunks, workgroup shape and the forward's saved state are unchanged.
+#include "mgs_render_common.h"
+
+namespace mgs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int F>
+struct GmCfg {
+  static constexpr int NCH = F + 3;                 // feature channels, then r, g, b
+  static constexpr int KCH = (NCH + 1) & ~1;        // channels padded to the MFMA's K = 2
+  static constexpr int NCT = (F + 31) / 32;         // 32-row tiles of the dL_dfeature contraction
+  static constexpr int SROW = (NCT > 0 ? NCT * 32 : 0) + 1;  // dLs row stride (odd: conflict-free column reads)
+};
+
+template <bool FAST>
+__device__ __forceinline__ float gm_exp(float x) { return exp_<FAST>(x); }
+
+// Per-wave LDS record of one compacted entry: {index into the tile's sorted instance list, 1-based position in the chunk}
+struct GmRec { float4 g0, g1; uint32_t id, pos; };
+
+template <int F, bool FAST, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const float4* __restrict__ inst,
+                                                          const uint32_t* __restrict__ last_chunk,
+                                                          const float* __restrict__ T_end,
+                                                          const uint32_t* __restrict__ last_pos,
+                                                          const float* __restrict__ partial, float* __restrict__ q,
+                                                          const float* __restrict__ final_T,
+                                                          const float* __restrict__ dL_dpix,
+                                                          const float* __restrict__ dL_dpix_F, float* __restrict__ acc8,
+                                                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat) {
+  using C = GmCfg<F>;
+  constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
+  __shared__ float dLT[KCH][64];          // [channel][pixel]: A operand of the D contraction
+  __shared__ float dLs[64 * SROW];        // [pixel][feature channel, zero padded]: A operand of the feature contraction
+  __shared__ float4 pd[NW][64];           // per wave, per pixel: {T_in, S_after + T_final*bg.dL, last (bits), T_in of group 1}
+  __shared__ float4 rec0[NW][64], rec1[NW][64];  // per wave: compacted entries of the current chunk (packed records)
+  __shared__ uint2 recid[NW][64];                // ... {Gaussian id, 1-based position in the chunk}
+  constexpr int TROW = NCT * 32 + 9;      // per wave: [32 Gaussians][feature sums | 9 scalar sums], odd stride
+  __shared__ float trbuf[NW][32 * TROW];
+  __shared__ uint32_t gid[NW][32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tile, sub;
+  map_block(blockIdx.x, tile, sub);
+  if (tile >= r.tiles_x * r.tiles_y) return;
+  const uint32_t lc = last_chunk[((size_t)tile * 4 + sub) * 64 + lane];
+  const uint32_t lcmax = wave_umax(lc);
+  if (lcmax == 0) return;
+  const PixBlk p = pix_blk(r, tile, sub, lane);
+  const uint2 rng = ranges[tile];
+  const bool use_feat = (F > 0) && r.include_feature;
+  const size_t HW = (size_t)r.H * r.W;
+  const size_t pix = (size_t)p.py * r.W + p.px;
+  const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+
+  // ---- pixel-lane prologue: dL of this block into LDS (both layouts), q[c] = dL . partial[c] ----
+  const float T_final = any ? final_T[pix] : 0.f;
+  float bgT = 0.f;
+  {
+    float dLc[3] = {0.f, 0.f, 0.f};
+    float dLf[F > 0 ? F : 1];
+#pragma unroll
+    for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
+    if (any) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[ch * HW + pix];
+      if constexpr (F > 0) {
+        if (use_feat) {
+#pragma unroll
+          for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[ch * HW + pix];
+        }
+      }
+    }
+    bgT = T_final * (r.bg[0] * dLc[0] + r.bg[1] * dLc[1] + r.bg[2] * dLc[2]);
+    if (w == 0) {
+      if constexpr (F > 0) {
+#pragma unroll
+        for (int ch = 0; ch < F; ch++) { dLT[ch][lane] = dLf[ch]; dLs[lane * SROW + ch] = dLf[ch]; }
+#pragma unroll
+        for (int ch = F; ch < NCT * 32; ch++) dLs[lane * SROW + ch] = 0.f;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) dLT[F + ch][lane] = dLc[ch];
+#pragma unroll
+      for (int ch = NCH; ch < KCH; ch++) dLT[ch][lane] = 0.f;
+    }
+    for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
+      const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+      float s = 0.f;
+      if (c < lc) {
+        const float* pp = partial + slot * NCH * 64 + lane;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) s += dLc[ch] * pp[ch * 64];
+        if constexpr (F > 0) {
+          if (use_feat) {
+#pragma unroll
+            for (int ch = 0; ch < F; ch++) s += dLf[ch] * pp[(3 + ch) * 64];
+          }
+        }
+      }
+      q[slot * 64 + lane] = s;
+    }
+  }
+  __syncthreads();  // dLT/dLs (LDS) and q (global, this workgroup only) are visible to every wave
+
+  const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.H;
+  const int n = lane & 31, h = lane >> 5;
+  const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
+
+  for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
+    // ---- pixel-lane: state of this chunk for my pixel ----
+    const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+    const uint32_t last = (c < lc) ? last_pos[slot * 64 + lane] : 0u;
+    const uint32_t kmax = wave_umax(last);
+    if (kmax == 0) continue;
+    const bool live = last > 0;
+    float B = 0.f;
+    for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
+      const float v = q[chunk_slot(rng.x, tile, CH, c2, sub) * 64 + lane];
+      B += (live && c2 < lc) ? v : 0.f;
+    }
+    const float T_in = (live && c > 0) ? T_end[chunk_slot(rng.x, tile, CH, c - 1, sub) * 64 + lane] : 1.0f;
+    // ---- entry-lane: cull + compact the chunk's entries that reach this 8x8 block ----
+    const uint32_t e = rng.x + c * (uint32_t)CH + (uint32_t)lane;
+    const bool valid = e < rng.y && (uint32_t)lane + 1u <= kmax;
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+    uint32_t id_e = 0;
+    if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; id_e = point_list[e]; }
+    const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
+    const unsigned long long smask = ballot(surv);
+    const int ns = __builtin_popcountll(smask);
+    if (ns == 0) continue;
+    wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
+    pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), 1.0f);
+    if (surv) {
+      const int rk = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
+      rec0[w][rk] = g0; rec1[w][rk] = g1; recid[w][rk] = make_uint2(id_e, (uint32_t)lane + 1u);
+    }
+    wave_lds_sync();
+    const int ngroups = (ns + 31) >> 5;
+
+    // ---- Gaussian-lane: groups of <= 32 entries, last group first (suffix sums run back to front) ----
+    for (int g = ngroups - 1; g >= 0; --g) {
+      const int gi = 32 * g + n;
+      const bool has = gi < ns;
+      GmRec rec;
+      {
+        const int ri = has ? gi : 0;
+        const uint2 re = recid[w][ri];
+        rec.g0 = rec0[w][ri]; rec.g1 = rec1[w][ri]; rec.id = re.x; rec.pos = re.y;
+      }
+      const float ex = rec.g0.x, ey = rec.g0.y, cx = rec.g0.z, cy = rec.g0.w, cz = rec.g1.x;
+      const float op = has ? rec.g1.y : 0.f;
+      const uint32_t pos = has ? rec.pos : 0xffffffffu;
+      const uint32_t id = rec.id;
+
+      if (g == 1) {
+        // group 1 starts from T_in * prod over group 0 of (1 - alpha): a light pass over group 0's entries
+        GmRec r0;  // group 0 is full when a group 1 exists
+        r0.g0 = rec0[w][n]; r0.g1 = rec1[w][n]; r0.pos = recid[w][n].y; r0.id = 0;
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+#pragma unroll 1
+          for (int rr = 0; rr < 16; rr++) {
+            const int pp = 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            const float4 st = pd[w][pp];
+            const float dx = r0.g0.x - (bx0 + (float)((rr & 3) + 4 * h));
+            const float dy = r0.g0.y - (by0 + (float)(4 * u + (rr >> 2)));
+            const float power = -0.5f * (r0.g0.z * dx * dx + r0.g1.x * dy * dy) - r0.g0.w * dx * dy;
+            const float alpha = fminf(0.99f, r0.g1.y * gm_exp<FAST>(power));
+            const bool act = r0.pos <= __float_as_uint(st.z) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float om = act ? 1.0f - alpha : 1.0f;
+            const float incl = half_excl_scan_mul(om, lane) * om;
+            const float tot = half_last(incl, lane);
+            if (n == 0) pd[w][pp].w = st.x * tot;
+          }
+        }
+        wave_lds_sync();
+      }
+
+      float a_mx = 0.f, a_my = 0.f, a_cx = 0.f, a_cy = 0.f, a_cz = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+      f32x16 Cf[NCT > 0 ? NCT : 1];
+#pragma unroll
+      for (int ct = 0; ct < (NCT > 0 ? NCT : 1); ct++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) Cf[ct][i] = 0.f;
+
+      // two passes of 16 pixels per lane (tile u = pixel rows 4u..4u+3 of the block); kept rolled so that only one
+      // D tile and no colour/feature row are live during the pixel steps
+#pragma unroll 1
+      for (int u = 0; u < 2; u++) {
+        // D = dL . row for my 16 pixels of this tile, on the matrix cores.  B operand: lane (n, h) feeds channel
+        // 2t + h of its Gaussian's row (features, then r, g, b, zero padding), straight from memory.
+        f32x16 Dt;
+        {
+          float bop[KCH / 2];
+#pragma unroll
+          for (int t = 0; t < KCH / 2; t++) {
+            const int c = 2 * t + h;
+            const float* src = (c < F && use_feat) ? r.feats + (size_t)id * F + c : r.colors + (size_t)id * 3 + (c - F);
+            const bool okc = has && ((c < F) ? use_feat : (c < F + 3));
+            bop[t] = okc ? *src : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) Dt[i] = 0.f;
+#pragma unroll
+          for (int t = 0; t < KCH / 2; t++) {
+            const float a = dLT[2 * t + h][32 * u + n];        // A[i = pixel n of tile u][k = h]
+            Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bop[t], Dt, 0, 0, 0);  // B[k = h][j = Gaussian n]
+          }
+        }
+        const float pyu = by0 + (float)(4 * u);
+#pragma unroll 1
+        for (int rr = 0; rr < 16; rr++) {  // rolled: one pixel step's worth of registers (Dt[rr]: uniform index)
+          const int pp = 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * h;  // my pixel of this step
+          const float4 st = pd[w][pp];
+          const float Tg = (g == 0) ? st.x : st.w;                   // transmittance entering this group
+          const float dx = ex - (bx0 + (float)((rr & 3) + 4 * h));
+          const float dy = ey - (pyu + (float)(rr >> 2));
+          const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+          const float G = gm_exp<FAST>(power);
+          const float alpha = fminf(0.99f, op * G);
+          const bool act = pos <= __float_as_uint(st.z) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float om = act ? 1.0f - alpha : 1.0f;
+          const float T = Tg * half_excl_scan_mul(om, lane);         // transmittance before my Gaussian
+          const float wa = act ? alpha * T : 0.f;
+          const float D = Dt[rr];
+          const float Dw = D * wa;
+          const float P = half_incl_scan_add(Dw);
+          const float tot = half_last(P, lane);
+          const float S = (tot - P) + st.y;                          // D*alpha*T of everything behind me (+ bg term)
+          if (g > 0 && n == 0) pd[w][pp].y = st.y + tot;             // group g-1 sees this group behind it
+          const float dL_dalpha = act ? D * T - S * __builtin_amdgcn_rcpf(om) : 0.f;
+          const float dL_dG = op * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          a_mx += dL_dG * (-gdx * cx - gdy * cy);
+          a_my += dL_dG * (-gdy * cz - gdx * cy);
+          a_cx += gdx * dx * dL_dG;
+          a_cy += gdx * dy * dL_dG;
+          a_cz += gdy * dy * dL_dG;
+          a_op += G * dL_dalpha;
+          a_r += wa * dLT[F][pp];
+          a_g += wa * dLT[F + 1][pp];
+          a_b += wa * dLT[F + 2][pp];
+          if constexpr (NCT > 0) {
+            if (use_feat) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ct++) {
+                const float a = dLs[pp * SROW + 32 * ct + n];        // A[i = channel 32ct+n][k = h]: my pixel's dL
+                Cf[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa, Cf[ct], 0, 0, 0);  // B[k = h][j = n] = wa
+              }
+            }
+          }
+        }
+      }
+      if (g > 0) wave_lds_sync();  // pd[].y updates visible before the next group reads them
+
+      // ---- hand the group's sums to memory: transpose through LDS so that every atomic instruction covers whole
+      //      rows (32 consecutive feature channels of one Gaussian = one 128-B line; 8 Gaussians x 6 geometry sums;
+      //      16 Gaussians x 3 colour sums) instead of 64 different lines ----
+      {
+        float v[9] = {a_mx * ddelx_dx, a_my * ddely_dy, -0.5f * a_cx, -0.5f * a_cy, -0.5f * a_cz, a_op, a_r, a_g, a_b};
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] += __uint_as_float(lane_xor<32>(__float_as_uint(v[i]), lane));
+        float* tr = trbuf[w];
+        if (h == 0) gid[w][n] = has ? id : 0xffffffffu;
+        if constexpr (NCT > 0) {
+          if (use_feat) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+              for (int i = 0; i < 16; i++)
+                tr[n * TROW + 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h] = Cf[ct][i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+          if ((i & 1) == h) tr[n * TROW + NCT * 32 + i] = v[i];
+        wave_lds_sync();
+        if constexpr (NCT > 0) {
+          if (use_feat) {
+#pragma unroll
+            for (int k = 0; k < 16 * NCT; k++) {  // instruction k: Gaussians 2k', 2k'+1 of the tile half, 32 channels each
+              const int gg = 2 * (k % 16) + h, ch = 32 * (k / 16) + n;
+              const uint32_t gi2 = gid[w][gg];
+              if (gi2 != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gi2 * F + ch, tr[gg * TROW + ch]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // geometry sums: 8 Gaussians x 8 slots (6 used) per instruction
+          const int gg = 8 * k + (lane >> 3), i = lane & 7;
+          const uint32_t gi2 = gid[w][gg];
+          if (gi2 != 0xffffffffu && i < 6) unsafeAtomicAdd(acc8 + (size_t)gi2 * 8 + i, tr[gg * TROW + NCT * 32 + i]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {  // colour sums: 16 Gaussians x 4 slots (3 used) per instruction
+          const int gg = 16 * k + (lane >> 2), i = lane & 3;
+          const uint32_t gi2 = gid[w][gg];
+          if (gi2 != 0xffffffffu && i < 3)
+            unsafeAtomicAdd(dL_dcolors + (size_t)gi2 * 3 + i, tr[gg * TROW + NCT * 32 + 6 + i]);
+        }
+        wave_lds_sync();  // tr / gid are rewritten by the next group
+      }
+    }
+  }
+}
+
+// ------------------------------------------- dispatch ------------------------------------------------
+template <int F>
+static hipError_t gm_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, const float* dc,
+                       const float* df, float* acc8, float* dcol, float* dfeat, hipStream_t s) {
+  const int T = r.tiles_x * r.tiles_y;
+  const int grid = ((T + 7) / 8) * 32;
+#define MGS_GM(FAST, EXACT, NW)                                                                                      \
+  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges,       \
+                     b.point_list, b.inst, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, \
+                     acc8, dcol, dfeat)
+  // 8 waves per workgroup: 256 registers per lane (no spills); 16 waves: more latency hiding, 128 registers
+  bool launched = false;
+  if constexpr (F <= 32) {
+    if (options().gm_waves != 8) {
+      if (r.fast_exp) { if (r.exact_cull) MGS_GM(true, true, 16); else MGS_GM(true, false, 16); }
+      else            { if (r.exact_cull) MGS_GM(false, true, 16); else MGS_GM(false, false, 16); }
+      launched = true;
+    }
+  }
+  if (!launched) {
+    if (r.fast_exp) MGS_GM(true, true, 8); else MGS_GM(false, true, 8);
+  }
+#undef MGS_GM
+  return hipGetLastError();
+}
+
+hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
+                                float* dL_dfeat, hipStream_t s) {
+  const int F = r.include_feature ? r.F : 0;
+  switch (F) {
+#define X(N) case N: return gm_F<N>(r, b, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, s);
+    MGS_FOR_EACH_F(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mgs

@@ -62,6 +62,75 @@ __device__ __forceinline__ bool overlaps_block(const float4& g0, const float4& g
          (g0.y - g1.w <= bymax);
 }
 
+// conservative EXACT-shape cull: does {q(d) <= tau} (tau = 2 ln(255 o), inflated) reach the pixel rectangle?
+// bbox test first; then the minimum of the quadratic form over the rectangle (on the boundary unless the
+// centre is inside).  Degenerate conics (marked by hx >= 1e5 in the preprocess) are never culled.
+__device__ __forceinline__ bool reaches_block(const float4& g0, const float4& g1, float bxmin, float bxmax,
+                                              float bymin, float bymax) {
+  if (!overlaps_block(g0, g1, bxmin, bxmax, bymin, bymax)) return false;
+  if (g1.z >= 1e5f) return true;
+  const float dx0 = bxmin - g0.x, dx1 = bxmax - g0.x, dy0 = bymin - g0.y, dy1 = bymax - g0.y;
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  const float cx = g0.z, cy = g0.w, cz = g1.x;
+  const float tau = 2.0f * __logf(fmaxf(g1.y * 255.0f, 1.0f)) * 1.001f + 2e-3f;
+  const float icz = 1.0f / cz, icx = 1.0f / cx;
+  float best = 3.0e38f;
+  {
+    const float dy = fminf(fmaxf(-cy * dx0 * icz, dy0), dy1);
+    best = fminf(best, cx * dx0 * dx0 + 2.f * cy * dx0 * dy + cz * dy * dy);
+  }
+  {
+    const float dy = fminf(fmaxf(-cy * dx1 * icz, dy0), dy1);
+    best = fminf(best, cx * dx1 * dx1 + 2.f * cy * dx1 * dy + cz * dy * dy);
+  }
+  {
+    const float dx = fminf(fmaxf(-cy * dy0 * icx, dx0), dx1);
+    best = fminf(best, cx * dx * dx + 2.f * cy * dx * dy0 + cz * dy0 * dy0);
+  }
+  {
+    const float dx = fminf(fmaxf(-cy * dy1 * icx, dx0), dx1);
+    best = fminf(best, cx * dx * dx + 2.f * cy * dx * dy1 + cz * dy1 * dy1);
+  }
+  return !(best > tau);
+}
+
+struct PixBlk {
+  int px, py;
+  bool inside;
+  float pxf, pyf, bxmin, bxmax, bymin, bymax;
+};
+__device__ __forceinline__ PixBlk pix_blk(const RenderArgs& r, int tile, int sub, int lane) {
+  PixBlk p;
+  const int tx = tile % r.tiles_x, ty = tile / r.tiles_x;
+  const int bx0 = tx * TILE + (sub & 1) * SUB, by0 = ty * TILE + (sub >> 1) * SUB;
+  p.px = bx0 + (lane & 7);
+  p.py = by0 + (lane >> 3);
+  p.inside = p.px < r.W && p.py < r.H;
+  p.pxf = (float)p.px; p.pyf = (float)p.py;
+  p.bxmin = (float)bx0; p.bxmax = (float)min(bx0 + SUB - 1, r.W - 1);
+  p.bymin = (float)by0; p.bymax = (float)min(by0 + SUB - 1, r.H - 1);
+  return p;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ bool cull_ok(const float4& g0, const float4& g1, const PixBlk& p) {
+  if constexpr (EXACT) return reaches_block(g0, g1, p.bxmin, p.bxmax, p.bymin, p.bymax);
+  else return overlaps_block(g0, g1, p.bxmin, p.bxmax, p.bymin, p.bymax);
+}
+
+// wave-private LDS hand-off (all LDS traffic of one wave executes in order; only the compiler must not reorder)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// storage index of chunk c of a tile whose list starts at x: floor(x/CH) + tile + c  (collision-free and
+// bounded by R/CH + T, so no prefix table is needed)
+__device__ __forceinline__ size_t chunk_slot(uint32_t range_x, int tile, int CH, uint32_t c, int sub) {
+  return ((size_t)(range_x / (uint32_t)CH) + (size_t)tile + c) * 4 + (size_t)sub;
+}
+
 // Feature widths compiled in.  Other widths are padded up by the host shim (zero channels change nothing).
 #define MGS_FOR_EACH_F(X) X(0) X(3) X(4) X(8) X(16) X(32) X(64)
 

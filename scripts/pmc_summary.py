@@ -9,6 +9,6 @@ for d in sys.argv[1:]:
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
     print("==", d)
     for k, c in agg.items():
-        if not any(s in k for s in ("chunk_", "coop_", "render_", "preprocess", "ranges", "duplicate", "bin_", "sort")):
+        if not any(s in k for s in ("chunk_", "coop_", "render_", "preprocess", "ranges", "duplicate", "bin_", "sort", "gm_")):
             continue
         print("  ", k, {n: round(v / cnt[(k, n)]) for n, v in c.items()})
