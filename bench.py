@@ -118,6 +118,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Autograd scheduling knob, results unchanged: run the backward on the calling thread instead of handing it
+    # to the engine's device thread (the hand-off costs ~50-100 us of host time per step on this node, which at
+    # ~0.25 ms per step is not noise).  DESIGN.md section 8.
+    torch.autograd.set_multithreading_enabled(False)
     for _ in range(args.warmup):
         step()
     sync_all()

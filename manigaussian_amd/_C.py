@@ -28,6 +28,8 @@ def _ptr(t):
 def _f32c(t, name, dev):
     """contiguous float32 on dev; empty tensors pass through (they become NULL pointers, like the
     reference's .data<float>() of an empty tensor)."""
+    if t.dtype is _F32 and t.device == dev and t.is_contiguous():  # the hot path: nothing to do
+        return t
     if t.numel() == 0:
         return t
     if t.dtype != _F32:
@@ -38,7 +40,23 @@ def _f32c(t, name, dev):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~10 us)."""
+
+    def __init__(self, dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefiltered, debug, include_feature,
@@ -119,7 +137,7 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
         if F != F_user:  # feature widths that are not compiled in: zero channels change nothing
             language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
 
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         u8 = dict(dtype=torch.uint8, device=dev)
         if P == 0:  # rasterize_points.cu:92: empty workspaces, zero images
             out_color = torch.zeros((3, H, W), dtype=_F32, device=dev)
@@ -191,7 +209,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, language_fe
             language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
             dL_dout_language_feature = torch.cat(
                 [dL_dout_language_feature, dL_dout_language_feature.new_zeros((F - F_user, H, W))], 0)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if P == 0:
             z = lambda *s_: torch.zeros(s_, dtype=_F32, device=dev)  # noqa: E731
             return (z(0, 3), z(0, 3), z(0, F_user) if include_feature else z(1), z(0, 1), z(0, 3), z(0, 6),

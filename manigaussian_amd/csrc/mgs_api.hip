@@ -184,9 +184,19 @@ size_t mgs_binning_bytes(int R, int W, int H, int F) {
 }
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
 
+static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy);
 // Largest instance capacity whose binning layout fits `bytes`: the layout of a binning workspace is a function
 // of its SIZE, so forward and backward agree on it whatever count the caller passes.
 static int binning_capacity(size_t bytes, int T, int F, bool legacy) {
+  struct Memo { size_t bytes; int T, F, ch, legacy, cap; };
+  static thread_local Memo memo = {0, -1, -1, -1, -1, -1};
+  if (memo.bytes == bytes && memo.T == T && memo.F == F && memo.ch == chunk_size() && memo.legacy == (int)legacy)
+    return memo.cap;
+  const int cap_ = binning_capacity_uncached(bytes, T, F, legacy);
+  memo = {bytes, T, F, chunk_size(), (int)legacy, cap_};
+  return cap_;
+}
+static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy) {
   auto need = [&](int R) { size_t t; carve_binning(nullptr, R, T, F, chunk_size(), legacy, nullptr, &t); return t; };
   if (need(0) > bytes) return -1;
   int lo = 0, hi = 1;

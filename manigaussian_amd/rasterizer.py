@@ -96,8 +96,11 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, language_feature_p
                                      scales, rotations, cov3Ds_precomp, raster_settings)
 
 
+_EMPTY = torch.Tensor([])  # the reference passes torch.Tensor([]) for absent inputs (__init__.py:207-219)
+
+
 def _or_empty(t):
-    return torch.Tensor([]) if t is None else t
+    return _EMPTY if t is None else t
 
 
 class GaussianRasterizer(nn.Module):

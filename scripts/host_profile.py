@@ -5,7 +5,7 @@ import torch
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
 from manigaussian_amd import synthetic as syn
 
-P, F, W = 100000, 32, 128
+P, F, W = int(os.environ.get("HP_P", "100000")), 32, 128
 dev = torch.device("cuda:0")
 sc = syn.make_scene(P, F=F, M=4, seed=0)
 cam = syn.circle_cameras(8, W, W, negative_focal=True)[0]
