@@ -14,7 +14,8 @@ buffer when N>1; weak scaling: every GPU renders its own view of the replicated 
 The JSON line also carries
   roofline:     the dominant kernel (render backward) timed live with HIP events on its launch stream,
                 achieved = algorithmic bytes (R*(112+12F) + N_pix*(20+4F)) / mean duration,
-                against the 8 TB/s HBM peak.
+                against the 8 TB/s HBM peak; traffic = measured HBM bytes per launch from the committed
+                rocprofv3 PMC passes of this command (profiles/pmc_traffic.json).
   cpu_baseline: Oracle B (oracle/mgs_oracle.c, a port: the reference has no CPU rasterizer) on the host
                 cores, same workload, a bounded number of fwd+bwd passes.
 """
@@ -74,6 +75,19 @@ def cpu_baseline(sc, cam, d_color, d_feat, P, max_seconds):
     return {"value": P / best, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} fwd+bwd passes of the same workload (1 view), best of {len(times)}: "
                       f"{best * 1e3:.1f} ms, OpenMP {cores} threads"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (profiles/pmc_traffic.json, written by scripts/pmc_to_json.py; rocprofv3 cannot run inside the bench)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for k, v in json.load(f)["kernels"].items():
+                if kernel in k:
+                    return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -177,8 +191,9 @@ def main():
                        "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": 1, "num_rendered_R": int(R),
                        "R_over_P": R / P, "tight_bins": _lib.get_option("tight_bins"),
                        "collective": "1 in-place all-reduce of the flat per-Gaussian gradient buffer" if n_gpus > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel (K8)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "K8 render backward (gm_bwd_kernel)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("gm_bwd_kernel"),
                          "algorithmic_bytes_per_launch": bytes_k8, "avg_launch_ms": bwd_avg_ms, "launches": bwd_n},
             "path_hbm": {"algorithmic_bytes_per_view": bytes_path,
                          "achieved_GBps": bytes_path * n_gpus / (ms_step * 1e-3) / 1e9,

@@ -141,6 +141,8 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "exact_cull")) o.exact_cull = value;
   else if (!strcmp(key, "bin_mode")) o.bin_mode = value;
   else if (!strcmp(key, "bwd_mode")) o.bwd_mode = value;
+  else if (!strcmp(key, "dbg")) o.dbg = value;
+  else if (!strcmp(key, "fwd_mode")) o.fwd_mode = value;
   else if (!strcmp(key, "gm_waves")) o.gm_waves = value;
   else if (!strcmp(key, "seg")) {
     if (value != 512 && value != 1024 && value != 2048) { set_error("seg must be 512, 1024 or 2048"); return MGS_ERR_INVALID_ARG; }
@@ -160,6 +162,7 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "exact_cull")) return o.exact_cull;
   if (!strcmp(key, "bin_mode")) return o.bin_mode;
   if (!strcmp(key, "bwd_mode")) return o.bwd_mode;
+  if (!strcmp(key, "fwd_mode")) return o.fwd_mode;
   if (!strcmp(key, "gm_waves")) return o.gm_waves;
   if (!strcmp(key, "seg")) return o.seg;
   set_error("unknown option %s", key);
@@ -300,7 +303,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   }
   RenderArgs r;
   r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull;
+  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
@@ -476,7 +479,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   if (R > 0) {
     RenderArgs r;
     r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull;
+    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
     r.bg = a->background;
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;

@@ -189,6 +189,8 @@ struct Options {
   int exact_cull = 1;      // render_mode 2: exact ellipse-vs-block cull on top of the bbox cull
   int bwd_mode = 1;        // render_mode 2, chunk 64: 1 = Gaussian-major backward (scans + fp32 MFMA), 0 = pixel-major + butterfly
   int gm_waves = 16;       // waves per workgroup of the Gaussian-major backward (8 or 16)
+  int dbg = 0;             // see RenderArgs::dbg
+  int fwd_mode = 1;        // render_mode 2, chunk 64: 1 = prefetching forward with the image sum in LDS, 0 = original
   int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: legacy rocPRIM scan + radix sort
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
 };
@@ -220,6 +222,7 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, c
 
 struct RenderArgs {
   int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, bwd_reduce, exact_cull;
+  int dbg;  // timing experiments only (results invalid when non-zero): bit0 skip blend, bit1 skip phase A, bit2 skip final sum, bit3 skip row staging
   const float* bg;
   const float* colors;   // [P,3] colors_precomp or geom.rgb
   const float* feats;    // [P,F]

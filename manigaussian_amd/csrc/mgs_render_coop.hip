@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
     const uint32_t e1 = min(e0 + (uint32_t)CH, rng.y);
     // ---- phase A: transmittance product of this chunk ----
     float tp = 1.0f;
-    if (has) {
+    if (has && !(r.dbg & 2)) {
       for (uint32_t k0 = e0; k0 < e1; k0 += 64) {
         const uint32_t e = k0 + lane;
         const bool valid = e < e1;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
         unsigned long long mask = ballot(surv);
         if (mask == 0) continue;
         wave_lds_sync();
-        if (surv) stage_row<F>(stage, lane, point_list[e], r.colors, use_feat ? r.feats : nullptr);
+        if (surv && !(r.dbg & 8)) stage_row<F>(stage, lane, point_list[e], r.colors, use_feat ? r.feats : nullptr);
         wave_lds_sync();
         while (mask) {
           const int j = __builtin_ctzll(mask);
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
           const bool term = cand && (test_T < 0.0001f);
           done = done || term;
           const bool blend = cand && !term;
-          if (ballot(blend) == 0) continue;
+          if (ballot(blend) == 0 || (r.dbg & 1)) continue;
           const float wgt = blend ? alpha * T : 0.f;
           const float4* row = stage + j * ROW4;
           if constexpr (F > 0) {
@@ -177,13 +177,203 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
   for (int ch = w; ch < NCH; ch += NW) {
     if (ch >= 3 && !use_feat) break;
     float sum = 0.f;
-    for (uint32_t c = 0; c < vismax; c++) {
+    for (uint32_t c = 0; c < ((r.dbg & 4) ? 0u : vismax); c++) {
       const float v = partial[chunk_slot(rng.x, tile, CH, c, sub) * NCH * 64 + (size_t)ch * 64 + lane];
       sum += (c < vis) ? v : 0.f;
     }
     if (p.inside) {
       if (ch < 3) out_color[ch * HW + pix] = sum + Tf * r.bg[ch];
       else out_feat[(ch - 3) * HW + pix] = sum;
+    }
+  }
+  if (w == 0) {
+    last_chunk[((size_t)tile * 4 + sub) * 64 + lane] = vis;
+    if (p.inside) final_T[pix] = Tf;
+  }
+}
+
+// ------------------------------------- forward, CH == 64 ---------------------------------------------
+// Same results as coop_fwd_kernel bit for bit (same per-pixel arithmetic, same chunk-order image sum); what
+// changes is WHEN things are fetched and where the image sum runs (measured on MI355X, C3: the version above
+// spends 14 us re-reading its own partial sums from global memory in a dependent loop and ~3 global round
+// trips per round on the critical path):
+//   * one 64-entry batch per chunk: the packed records, the cull mask and the Gaussian id are loaded once per
+//     round and kept in registers for both phases;
+//   * the colour/feature rows of the surviving entries are gathered into the wave's LDS stage BEFORE phase A,
+//     so the gather's latency hides behind the transmittance products;
+//   * after phase B every wave parks its chunk's partial colours in its own (now free) LDS stage and the
+//     image is accumulated across waves in chunk order from LDS, channels split over the waves; the global
+//     partial[] stores stay (the backward needs them) but nothing reads them back here.
+template <int F, bool FAST, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ inst, float* __restrict__ T_end,
+                                                              uint32_t* __restrict__ last_pos, float* __restrict__ partial,
+                                                              float* __restrict__ final_T, uint32_t* __restrict__ last_chunk,
+                                                              float* __restrict__ out_color, float* __restrict__ out_feat) {
+  constexpr int CH = 64;
+  constexpr int ROW4 = Row<F>::ROW4;
+  constexpr int NCH = F + 3;
+  constexpr int STAGE4 = 64 * ROW4;  // float4 per wave
+  constexpr int NOWN = (NCH + NW - 1) / NW;  // image channels owned by one wave
+  __shared__ float4 lds[NW * STAGE4];
+  __shared__ float Tp[NW][64];
+  __shared__ float red_Tf[64];
+  __shared__ uint32_t red_vis[64];
+  __shared__ uint32_t entered[NW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tile, sub;
+  map_block(blockIdx.x, tile, sub);
+  if (tile >= r.tiles_x * r.tiles_y) return;
+  const PixBlk p = pix_blk(r, tile, sub, lane);
+  const uint2 rng = ranges[tile];
+  const uint32_t len = rng.y - rng.x;
+  const uint32_t nch = (len + (uint32_t)CH - 1u) / (uint32_t)CH;
+  const bool use_feat = (F > 0) && r.include_feature;
+  float4* stage = lds + w * STAGE4;
+  float* stage_f = reinterpret_cast<float*>(stage);
+
+  float Tround = 1.0f;
+  uint32_t my_vis = 0;
+  float my_Tf = 1.0f;
+  float img[NOWN];
+#pragma unroll
+  for (int k = 0; k < NOWN; k++) img[k] = 0.f;
+
+  for (uint32_t r0 = 0; r0 < nch; r0 += NW) {
+    const uint32_t c = r0 + (uint32_t)w;
+    const bool has = c < nch;
+    const uint32_t e = rng.x + c * (uint32_t)CH + (uint32_t)lane;
+    const bool valid = has && e < rng.y;
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+    uint32_t id = 0;
+    if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; id = point_list[e]; }
+    const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
+    const unsigned long long smask = ballot(surv);
+    // rows of the survivors -> LDS (the previous round's readers of this stage passed the round's last barrier)
+    if (surv) stage_row<F>(stage, lane, id, r.colors, use_feat ? r.feats : nullptr);
+    // ---- phase A: transmittance product of this chunk ----
+    float tp = 1.0f;
+    {
+      unsigned long long mask = smask;
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+        const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+        const float op = bcast_lane(g1.y, j);
+        const float dx = ex - p.pxf, dy = ey - p.pyf;
+        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+        const float alpha = fminf(0.99f, op * exp_<FAST>(power));
+        const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
+        tp = skip ? tp : tp * (1.0f - alpha);
+      }
+    }
+    Tp[w][lane] = tp;
+    __syncthreads();
+    // ---- prefix in chunk order (identical arithmetic in every wave) ----
+    float T = Tround;
+    for (int w2 = 0; w2 < w; w2++) T *= Tp[w2][lane];
+    float Tnext = T;
+    for (int w2 = w; w2 < NW; w2++) Tnext *= Tp[w2][lane];
+    // ---- phase B: blend this chunk ----
+    const bool live = has && p.inside && !(T < 0.0001f);
+    const bool enter = ballot(live) != 0;
+    if (enter) {
+      bool done = !live;
+      float C[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; i++) C[i] = 0.f;
+      uint32_t last = 0;
+      wave_lds_sync();  // this wave's stage rows are written
+      unsigned long long mask = smask;
+      while (mask) {
+        if (ballot(!done) == 0) break;
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+        const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+        const float op = bcast_lane(g1.y, j);
+        const float dx = ex - p.pxf, dy = ey - p.pyf;
+        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+        const float alpha = fminf(0.99f, op * exp_<FAST>(power));
+        const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
+        const float test_T = T * (1.0f - alpha);
+        const bool cand = !done && !skip;
+        const bool term = cand && (test_T < 0.0001f);
+        done = done || term;
+        const bool blend = cand && !term;
+        if (ballot(blend) == 0) continue;
+        const float wgt = blend ? alpha * T : 0.f;
+        const float4* row = stage + j * ROW4;
+        if constexpr (F > 0) {
+          if (use_feat) {
+            if constexpr (F % 4 == 0) {
+#pragma unroll
+              for (int i = 0; i < F / 4; i++) {
+                const float4 v = row[i];
+                C[3 + 4 * i] += v.x * wgt; C[3 + 4 * i + 1] += v.y * wgt;
+                C[3 + 4 * i + 2] += v.z * wgt; C[3 + 4 * i + 3] += v.w * wgt;
+              }
+            } else {
+              const float* rf = reinterpret_cast<const float*>(row);
+#pragma unroll
+              for (int i = 0; i < F; i++) C[3 + i] += rf[i] * wgt;
+            }
+          }
+        }
+        {
+          const float* rf = reinterpret_cast<const float*>(row);
+          C[0] += rf[F] * wgt; C[1] += rf[F + 1] * wgt; C[2] += rf[F + 2] * wgt;
+        }
+        T = blend ? test_T : T;
+        last = blend ? (uint32_t)j + 1u : last;
+      }
+      const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+      T_end[slot * 64 + lane] = T;
+      last_pos[slot * 64 + lane] = last;
+      float* pp = partial + slot * NCH * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
+      if (live) { my_vis = c + 1; my_Tf = T; }
+      wave_lds_sync();  // every lane is done reading the stage rows
+#pragma unroll
+      for (int i = 0; i < NCH; i++) stage_f[i * 64 + lane] = C[i];
+    }
+    if (lane == 0) entered[w] = enter ? 1u : 0u;
+    __syncthreads();
+    // ---- image += this round's partial colours, in chunk order; wave w owns channels w, w + NW, ... ----
+#pragma unroll
+    for (int k = 0; k < NOWN; k++) {
+      const int ch = w + k * NW;
+      if (ch < NCH && (ch < 3 || use_feat)) {
+        float acc = img[k];
+        for (int w2 = 0; w2 < NW; w2++)
+          if (entered[w2]) acc += reinterpret_cast<const float*>(lds + w2 * STAGE4)[ch * 64 + lane];
+        img[k] = acc;
+      }
+    }
+    __syncthreads();  // Tp, entered and the stages are rewritten next round
+    Tround = Tnext;
+    if (ballot(p.inside && !(Tround < 0.0001f)) == 0) break;
+  }
+
+  if (w == 0) { red_vis[lane] = 0; red_Tf[lane] = 1.0f; }
+  __syncthreads();
+  if (my_vis > 0) atomicMax(&red_vis[lane], my_vis);
+  __syncthreads();
+  const uint32_t vis = red_vis[lane];
+  if (my_vis > 0 && my_vis == vis) red_Tf[lane] = my_Tf;  // exactly one wave owns the last visited chunk
+  __syncthreads();
+  const float Tf = red_Tf[lane];
+  const size_t HW = (size_t)r.H * r.W;
+  const size_t pix = (size_t)p.py * r.W + p.px;
+  if (p.inside) {
+#pragma unroll
+    for (int k = 0; k < NOWN; k++) {
+      const int ch = w + k * NW;
+      if (ch < 3) out_color[ch * HW + pix] = img[k] + Tf * r.bg[ch];
+      else if (ch < NCH && use_feat) out_feat[(ch - 3) * HW + pix] = img[k];
     }
   }
   if (w == 0) {
@@ -404,8 +594,15 @@ static hipError_t fwd_F(const RenderArgs& r, const BinView& b, const ImgView& im
 #define MGS_CF(FAST, EXACT)                                                                                         \
   hipLaunchKernelGGL((coop_fwd_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges,    \
                      b.point_list, b.inst, cv.T_end, cv.last_pos, cv.partial, im.final_T, cv.last_chunk, oc, of)
-  if (r.fast_exp) { if (r.exact_cull) MGS_CF(true, true); else MGS_CF(true, false); }
+#define MGS_CF64(FAST, EXACT)                                                                                       \
+  hipLaunchKernelGGL((coop_fwd64_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges,          \
+                     b.point_list, b.inst, cv.T_end, cv.last_pos, cv.partial, im.final_T, cv.last_chunk, oc, of)
+  if (cv.CH == 64 && r.dbg == 0 && options().fwd_mode == 1) {
+    if (r.fast_exp) { if (r.exact_cull) MGS_CF64(true, true); else MGS_CF64(true, false); }
+    else            { if (r.exact_cull) MGS_CF64(false, true); else MGS_CF64(false, false); }
+  } else if (r.fast_exp) { if (r.exact_cull) MGS_CF(true, true); else MGS_CF(true, false); }
   else            { if (r.exact_cull) MGS_CF(false, true); else MGS_CF(false, false); }
+#undef MGS_CF64
 #undef MGS_CF
   return hipGetLastError();
 }

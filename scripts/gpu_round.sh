@@ -14,3 +14,4 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python scripts/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
+python scripts/pmc_to_json.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json
