@@ -91,6 +91,88 @@ def test_reference_reduction_variant_agrees():
     _lib.set_option("bwd_reduce", 1)
 
 
+_DEFAULTS = dict(render_mode=2, chunk=64, fwd_mode=1, bwd_mode=1, gm_waves=16, bin_mode=1, seg=2048, exact_cull=1,
+                 fast_exp=1, tight_bins=1)
+VARIANTS = {
+    "legacy_rocprim_binning": dict(bin_mode=0),
+    "segments_512": dict(seg=512), "segments_1024": dict(seg=1024),
+    "pixel_major_backward": dict(bwd_mode=0),
+    "gaussian_major_backward_8_waves": dict(gm_waves=8),
+    "original_forward": dict(fwd_mode=0),
+    "chunk_128_generic_kernels": dict(chunk=128),
+    "per_block_walk": dict(render_mode=0),
+    "chunk_items": dict(render_mode=1, chunk=128),
+    "ocml_expf_bbox_cull": dict(fast_exp=0, exact_cull=0),
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_kernel_variants_agree_with_oracle(name):
+    """Every A/B switch (mgs_set_option) selects another implementation of the same result contract."""
+    try:
+        for k, v in VARIANTS[name].items():
+            _lib.set_option(k, v)
+        _check(dict(P=6000, F=32))
+        _check(dict(P=3000, F=3, cov3d=True, W=72, H=40))
+    finally:
+        for k, v in _DEFAULTS.items():
+            _lib.set_option(k, v)
+
+
+def test_capacity_retry_and_two_call_path_match_fused_forward():
+    """The fused forward sizes the binning workspace from a guess; when the guess is too small it reports
+    MGS_NEED_CAPACITY and the shim re-bins with the exact count.  The reference-shaped two-call path
+    (preprocess -> host read-back -> render) must give the same images as both."""
+    import ctypes
+    from manigaussian_amd import _C
+    dev = torch.device("cuda:0")
+    sc, cam, kw, dC, dF = util.scene_case(P=5000, F=32)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    kwd = syn.camera_settings_kwargs(cam, 1, True, bg=(0.1, 0.2, 0.3), device=dev)
+    e = torch.Tensor([])
+
+    def fwd():
+        return _C.rasterize_gaussians(kwd["bg"], d["means3D"], e, d["language_feature"], d["opacities"], d["scales"],
+                                      d["rotations"], 1.0, e, kwd["viewmatrix"], kwd["projmatrix"], kwd["tanfovx"],
+                                      kwd["tanfovy"], 128, 128, d["shs"], 1, kwd["campos"], False, False, True)
+
+    R0, c0, f0, r0 = fwd()[:4]
+    st = _C._dev_state(dev)
+    key = (5000, 128, 128, 32)
+    assert st["cap"][key] >= R0
+    st["cap"][key] = 64                      # far too small: forces the retry
+    R1, c1, f1, r1 = fwd()[:4]
+    assert R1 == R0 and torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+    assert st["cap"][key] >= R0              # the high-water mark was learnt again
+    # two-call path through the C ABI
+    L = _lib.lib()
+    u8 = dict(dtype=torch.uint8, device=dev)
+    geom = torch.empty(L.mgs_geom_bytes(5000, 4, 128, 128), **u8)
+    img = torch.empty(L.mgs_img_bytes(128, 128), **u8)
+    a = _lib.MgsRasterArgs()
+    _C._fill_args(a, P=5000, D=1, M=4, F=32, W=128, H=128, tanfovx=kwd["tanfovx"], tanfovy=kwd["tanfovy"],
+                  scale_modifier=1.0, prefiltered=False, debug=False, include_feature=True, background=kwd["bg"],
+                  means3D=d["means3D"], sh=d["shs"], colors=e, language_feature=d["language_feature"],
+                  opacity=d["opacities"], scales=d["scales"], rotations=d["rotations"], cov3D_precomp=e,
+                  viewmatrix=kwd["viewmatrix"], projmatrix=kwd["projmatrix"], campos=kwd["campos"], geom=geom,
+                  binning=None, img=img)
+    radii = torch.empty(5000, dtype=torch.int32, device=dev)
+    nr = ctypes.c_int32(0)
+    _lib.check(L.mgs_rasterize_forward_preprocess(ctypes.byref(a), radii.data_ptr(), ctypes.byref(nr), None), "pre")
+    assert nr.value == R0 and torch.equal(radii, r0)
+    binning = torch.empty(L.mgs_binning_bytes(nr.value, 128, 128, 32), **u8)
+    a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
+    c2, f2 = torch.empty_like(c0), torch.empty_like(f0)
+    _lib.check(L.mgs_rasterize_forward_render(ctypes.byref(a), nr.value, radii.data_ptr(), c2.data_ptr(), f2.data_ptr(),
+                                              None), "render")
+    torch.cuda.synchronize()
+    assert torch.equal(c2, c0) and torch.equal(f2, f0)
+    # a binning workspace that is too small is refused, not overrun
+    a.binning_bytes = L.mgs_binning_bytes(nr.value // 2, 128, 128, 32)
+    assert L.mgs_rasterize_forward_render(ctypes.byref(a), nr.value, radii.data_ptr(), c2.data_ptr(), f2.data_ptr(),
+                                          None) == _lib.MGS_ERR_WORKSPACE
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_vectors(path):
     z = np.load(path)
