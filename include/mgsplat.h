@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 2
+#define MGS_ABI_VERSION 3
 
 /* error codes */
 #define MGS_OK 0
@@ -78,6 +78,11 @@ typedef struct MgsRasterArgs {
   void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M, W, H)      */
   void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H, F); forward and backward must pass the SAME size */
   void* img;     size_t img_bytes;      /* >= mgs_img_bytes(W, H)             */
+  /* Optional: the accumulator block of a LATER backward (its scratch followed by dL_dcolors and dL_dfeature,
+   * contiguous, a multiple of 16 bytes).  Forward: if non-NULL the preprocess kernel zeroes it on the side, so the
+   * backward needs no fill.  Backward: accum_prezeroed != 0 promises exactly that (and that nothing touched it since). */
+  void* bwd_accum; size_t bwd_accum_bytes;
+  int32_t accum_prezeroed;
 } MgsRasterArgs;
 
 int mgs_abi_version(void);

@@ -100,12 +100,31 @@ def _remember_capacity(st, key, R):
         st["cap"][key] = want
 
 
+def _grad_layout(L, P, M, F):
+    """Float offsets of the backward's single allocation: [scratch | dL_dcolors | dL_dfeature | means3D | means2D |
+    opacity | cov3D | sh | scales | rotations | pad].  The first three regions are the accumulators."""
+    scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
+    sizes = [scratch_f, 3 * P, F * P, 3 * P, 3 * P, P, 6 * P, 3 * M * P, 3 * P, 4 * P, 4]
+    accum_bytes = ((scratch_f + 3 * P + F * P) * 4 + 15) // 16 * 16  # may reach into the next, fully rewritten, region
+    return sizes, accum_bytes
+
+
 def rasterize_gaussians(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
                         degree, campos, prefiltered, debug, include_feature):
     """RasterizeGaussiansCUDA (RAST/rasterize_points.cu:35-128).
     Returns (num_rendered, out_color [3,H,W], out_language_feature [F,H,W] or [1], radii [P] int32,
              geomBuffer, binningBuffer, imgBuffer)."""
+    return _forward(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
+                    cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                    campos, prefiltered, debug, include_feature, False)[:7]
+
+
+def _forward(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+             debug, include_feature, want_grad_buffer):
+    """rasterize_gaussians + (want_grad_buffer) the backward's allocation, whose accumulator block the forward's
+    preprocess kernel zeroes on the side: returns the 7-tuple + (grad_buffer or None,)."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
@@ -143,7 +162,8 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
             out_color = torch.zeros((3, H, W), dtype=_F32, device=dev)
             out_feat = torch.zeros((F_user, H, W) if include_feature else (1,), dtype=_F32, device=dev)
             e = torch.empty((0,), **u8)
-            return 0, out_color, out_feat, torch.zeros((0,), dtype=torch.int32, device=dev), e, e.clone(), e.clone()
+            return (0, out_color, out_feat, torch.zeros((0,), dtype=torch.int32, device=dev), e, e.clone(), e.clone(),
+                    None)
         out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
         out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
             torch.zeros((1,), dtype=_F32, device=dev)
@@ -161,6 +181,11 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
                    language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
                    cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos,
                    geom=geom, binning=binning, img=img)
+        grad_buffer = None
+        if want_grad_buffer:
+            sizes, accum_bytes = _grad_layout(L, P, M, F)
+            grad_buffer = torch.empty((sum(sizes),), dtype=_F32, device=dev)
+            a.bwd_accum, a.bwd_accum_bytes = grad_buffer.data_ptr(), accum_bytes
         stream = _stream(dev)
         nr = ctypes.c_int32(0)
         feat_ptr = out_feat.data_ptr() if include_feature else None
@@ -176,7 +201,7 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
         _remember_capacity(st, key, R)
     if include_feature and F != F_user:
         out_feat = out_feat[:F_user].contiguous()
-    return R, out_color, out_feat, radii, geom, binning, img
+    return R, out_color, out_feat, radii, geom, binning, img, grad_buffer
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, language_feature, scales, rotations,
@@ -186,6 +211,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, language_fe
     """RasterizeGaussiansBackwardCUDA (RAST/rasterize_points.cu:130-225).
     Returns (dL_dmeans2D [P,3], dL_dcolors [P,3], dL_dlanguage_feature [P,F] or [1], dL_dopacity [P,1],
              dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4])."""
+    return _backward(background, means3D, radii, colors, language_feature, scales, rotations, scale_modifier,
+                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                     dL_dout_language_feature, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                     include_feature, None)
+
+
+def _backward(background, means3D, radii, colors, language_feature, scales, rotations, scale_modifier, cov3D_precomp,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language_feature, sh, degree, campos,
+              geomBuffer, R, binningBuffer, imageBuffer, debug, include_feature, grad_buffer):
+    """rasterize_gaussians_backward; grad_buffer = the allocation _forward() handed out (accumulators already
+    zeroed by the forward's preprocess kernel) or None."""
     L = _lib.lib()
     dev = means3D.device
     P = int(means3D.size(0))
@@ -217,12 +253,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, language_fe
         # ONE allocation for the scratch accumulators and every gradient: the three regions the render backward
         # accumulates into (acc8 | dL_dcolors | dL_dfeature) come first and are contiguous, so the library zeroes
         # them with a single fill; everything else is fully written by the kernels.
-        scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
-        sizes = [scratch_f, 3 * P, F * P, 3 * P, 3 * P, P, 6 * P, 3 * M * P, 3 * P, 4 * P]
-        flat = torch.empty((sum(sizes),), dtype=_F32, device=dev)
-        (scratch, g_colors, g_feat, g_means3D, g_means2D, g_opacity, g_cov3D, g_sh, g_scales,
-         g_rot) = flat.split_with_sizes(sizes)
+        sizes, _ = _grad_layout(L, P, M, F)
+        prezeroed = grad_buffer is not None and grad_buffer.numel() == sum(sizes)
+        flat = grad_buffer if prezeroed else torch.empty((sum(sizes),), dtype=_F32, device=dev)
+        (scratch, g_colors, g_feat, g_means3D, g_means2D, g_opacity, g_cov3D, g_sh, g_scales, g_rot,
+         _pad) = flat.split_with_sizes(sizes)
         a = _lib.MgsRasterArgs()
+        a.accum_prezeroed = 1 if prezeroed else 0
         _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
                    scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
                    include_feature=include_feature, background=_f32c(background, "background", dev),

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -32,6 +32,7 @@ class MgsRasterArgs(ctypes.Structure):
         ("cov3D_precomp", c_fp), ("viewmatrix", c_fp), ("projmatrix", c_fp), ("campos", c_fp),
         ("geom", c_fp), ("geom_bytes", c_sz), ("binning", c_fp), ("binning_bytes", c_sz),
         ("img", c_fp), ("img_bytes", c_sz),
+        ("bwd_accum", c_fp), ("bwd_accum_bytes", c_sz), ("accum_prezeroed", c_i32),
     ]
 
 

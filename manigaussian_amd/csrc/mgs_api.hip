@@ -239,6 +239,15 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
   segsort = segsort_binning(p.tiles_x * p.tiles_y);
   MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
+  p.zero_ptr = nullptr; p.zero_f4 = 0;
+  if (a->bwd_accum) {
+    if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
+      set_error("bwd_accum must be 16-byte aligned and a multiple of 16 bytes");
+      return MGS_ERR_INVALID_ARG;
+    }
+    p.zero_ptr = reinterpret_cast<float4*>(a->bwd_accum);
+    p.zero_f4 = a->bwd_accum_bytes / 16;
+  }
   p.tile_hist = segsort ? im.tile_hist : nullptr;
   p.blk_base = segsort ? g.blk_base : nullptr;
   { StageTimer t(ST_PREPROCESS, stream);
@@ -460,6 +469,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   // dL_dcolors is the gradient w.r.t. the per-Gaussian RGB whether it came from colors_precomp or from SH
   // (the reference returns it in both cases, rasterize_points.cu:169,224)
   float* dcol = dL_dcolors;
+  if (!a->accum_prezeroed)
   { StageTimer t(ST_BWD_MEMSET, stream);
     // one fill when the caller laid acc8 | dL_dcolors | dL_dfeature out back to back (manigaussian_amd/_C.py does)
     char* z0 = reinterpret_cast<char*>(sc.acc8);

@@ -52,9 +52,8 @@ __device__ __forceinline__ void get_rect_b(float px, float py, int rad, int gx, 
   y1 = min(gy, max(0, (int)((py + rad + TILE - 1) / TILE)));
 }
 
-__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const float2* __restrict__ means2D,
+__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const float4* __restrict__ rec,
                                                                   const float* __restrict__ depths,
-                                                                  const float2* __restrict__ cullext,
                                                                   const uint32_t* __restrict__ offsets,
                                                                   const int32_t* __restrict__ radii,
                                                                   uint64_t* __restrict__ keys,
@@ -67,11 +66,13 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const f
   uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
   const uint32_t end = offsets[idx];
   if (off == end) return;
-  const float2 p = means2D[idx];
+  const float4 r0 = rec[2 * (size_t)idx];
+  const float2 p = make_float2(r0.x, r0.y);
   int x0, y0, x1, y1;
   get_rect_b(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
   if (tight_bins) {
-    const float2 h = cullext[idx];
+    const float4 r1 = rec[2 * (size_t)idx + 1];
+    const float2 h = make_float2(r1.z, r1.w);
     if (h.x < 0.f) return;
     const int tx0 = (int)ceilf((p.x - h.x - (TILE - 1)) / TILE), tx1 = (int)floorf((p.x + h.x) / TILE) + 1;
     const int ty0 = (int)ceilf((p.y - h.y - (TILE - 1)) / TILE), ty1 = (int)floorf((p.y + h.y) / TILE) + 1;
@@ -93,9 +94,7 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const f
 // ranges (rasterizer_impl.cu:116-138) + gather of the packed sorted instance records.
 __global__ void __launch_bounds__(256) ranges_gather_kernel(int L, const uint64_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ point_list,
-                                                            const float2* __restrict__ means2D,
-                                                            const float4* __restrict__ conic_opacity,
-                                                            const float2* __restrict__ cullext,
+                                                            const float4* __restrict__ rec,
                                                             uint2* __restrict__ ranges, float4* __restrict__ inst) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L) return;
@@ -111,11 +110,8 @@ __global__ void __launch_bounds__(256) ranges_gather_kernel(int L, const uint64_
   }
   if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
   const uint32_t id = point_list[idx];
-  const float2 xy = means2D[id];
-  const float4 co = conic_opacity[id];
-  const float2 h = cullext[id];
-  inst[2 * (size_t)idx] = make_float4(xy.x, xy.y, co.x, co.y);
-  inst[2 * (size_t)idx + 1] = make_float4(co.z, co.w, h.x, h.y);
+  inst[2 * (size_t)idx] = rec[2 * (size_t)id];
+  inst[2 * (size_t)idx + 1] = rec[2 * (size_t)id + 1];
 }
 
 // rasterizer_impl.cu:35-50
@@ -134,8 +130,8 @@ hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& 
   hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)tiles_x * tiles_y, s);
   if (e != hipSuccess) return e;
   if (R <= 0 || P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.means2D, g.depths,
-                     g.cullext, g.point_offsets, radii, b.keys_unsorted, b.vals_unsorted, tiles_x, tiles_y,
+  hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.depths,
+                     g.point_offsets, radii, b.keys_unsorted, b.vals_unsorted, tiles_x, tiles_y,
                      tight_bins);
   return hipGetLastError();
 }
@@ -150,8 +146,8 @@ hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStr
 
 hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im, int R, hipStream_t s) {
   if (R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ranges_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, b.point_list, g.means2D,
-                     g.conic_opacity, g.cullext, im.ranges, b.inst);
+  hipLaunchKernelGGL(ranges_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, b.point_list, g.rec,
+                     im.ranges, b.inst);
   return hipGetLastError();
 }
 
@@ -343,15 +339,16 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t* a, uint32_t 
   return pos;
 }
 
-// Rank of every key of this segment among the tile's other segments, staged through LDS in groups of whole
-// segments (<= CAP keys); then emission.  Two keys per thread.
+// K6': final position of a key = its index + its lower-bound rank in the tile's other segments (keys are unique),
+// staged through LDS in groups of whole segments (<= CAP keys); then emission of the sorted ids and of the packed
+// instance records (gathered early so the gather overlaps the ranking).  One workgroup per segment, two keys per thread.
+// (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores was measured at 45 us
+//  against 19 us for this one at C3: 64 tiles cannot keep 256 CUs busy.)
 template <int SEGN>
 __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
                                                                    const uint4* __restrict__ seg_desc,
                                                                    const uint64_t* __restrict__ keys,
-                                                                   const float2* __restrict__ means2D,
-                                                                   const float4* __restrict__ conic_opacity,
-                                                                   const float2* __restrict__ cullext,
+                                                                   const float4* __restrict__ rec,
                                                                    uint32_t* __restrict__ point_list,
                                                                    float4* __restrict__ inst) {
   constexpr uint32_t NT = SEGN / 2;
@@ -373,14 +370,12 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     rank[e] = i;
   }
   // the per-Gaussian record only depends on the id: fetch it now so the gather overlaps the ranking
-  float2 xy[2], h[2];
-  float4 co[2];
+  float4 r0[2], r1[2];
 #pragma unroll
   for (int e = 0; e < 2; e++) {
     const uint32_t id = (tid + e * NT) < cnt ? (uint32_t)key[e] : 0u;
-    xy[e] = means2D[id];
-    co[e] = conic_opacity[id];
-    h[e] = cullext[id];
+    r0[e] = rec[2 * (size_t)id];
+    r1[e] = rec[2 * (size_t)id + 1];
   }
   if (ns > 1) {
     const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
@@ -406,10 +401,10 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
       for (uint32_t s2 = s0; s2 < s1; s2++) {
         if (s2 == self) continue;
         const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
-        const uint32_t r0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
-        const uint32_t r1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
-        rank[0] += r0;
-        rank[1] += r1;
+        const uint32_t q0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
+        const uint32_t q1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
+        rank[0] += q0;
+        rank[1] += q1;
       }
     }
   }
@@ -419,8 +414,8 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     if (i >= cnt) continue;
     const size_t out = (size_t)start + rank[e];
     point_list[out] = (uint32_t)key[e];
-    inst[2 * out] = make_float4(xy[e].x, xy[e].y, co[e].x, co[e].y);
-    inst[2 * out + 1] = make_float4(co[e].z, co[e].w, h[e].x, h[e].y);
+    inst[2 * out] = r0[e];
+    inst[2 * out + 1] = r1[e];
   }
 }
 
@@ -430,7 +425,7 @@ static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView
   hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
                      b.keys_unsorted, b.keys);
   hipLaunchKernelGGL(bin_merge_emit_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                     b.keys, g.means2D, g.conic_opacity, g.cullext, b.point_list, b.inst);
+                     b.keys, g.rec, b.point_list, b.inst);
 }
 
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int P, int capacity, int tiles_x,

@@ -36,9 +36,9 @@ struct Carver {
 // Per-Gaussian state written by the forward preprocess (SoA).
 struct GeomView {
   float* depths;            // [P]   view-space z
-  float2* means2D;          // [P]   pixel coordinates
-  float4* conic_opacity;    // [P]   conic.x, conic.y, conic.z, opacity
-  float2* cullext;          // [P]   half extents (px) of the bbox of {alpha >= 1/255}; <0: never visible
+  float4* rec;              // [2P]  packed per-Gaussian record, the unit the binning gathers:
+                            //       {x, y (pixels), conic.x, conic.y} {conic.z, opacity, hx, hy}; hx, hy = half extents (px)
+                            //       of the bbox of {alpha >= 1/255}, <0: never visible
   float* rgb;               // [3P]  SH -> RGB (unused with colors_precomp)
   float* cov3D;             // [6P]
   uint8_t* clamped;         // [P]   bit c set: SH colour channel c was clamped at 0
@@ -98,9 +98,7 @@ inline GeomView carve_geom(void* p, int P, int M, int T, size_t* total) {
   GeomView g;
   size_t Pa = P > 0 ? (size_t)P : 1;
   g.depths = c.take<float>(Pa);
-  g.means2D = c.take<float2>(Pa);
-  g.conic_opacity = c.take<float4>(Pa);
-  g.cullext = c.take<float2>(Pa);
+  g.rec = c.take<float4>(2 * Pa);
   g.rect = c.take<uint2>(Pa);
   g.rgb = c.take<float>(3 * Pa);
   g.cov3D = c.take<float>(6 * Pa);
@@ -124,11 +122,12 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.final_T = c.take<float>(N ? N : 1);
   v.n_contrib = c.take<uint32_t>(N ? N : 1);
   v.ranges = c.take<uint2>(T ? T : 1);
-  v.flags = c.take<uint32_t>(4 + 3 * (T ? T : 1) + 1);  // flags | hist | cursor | seg_base, contiguous
+  const size_t nz = (4 + 3 * (T ? T : 1) + 1 + 63) & ~(size_t)63;  // whole 256-B units: one fill kernel, no tail
+  v.flags = c.take<uint32_t>(nz);  // flags | hist | cursor | seg_base, contiguous
   v.tile_hist = v.flags ? v.flags + 4 : nullptr;
   v.tile_cursor = v.flags ? v.tile_hist + (T ? T : 1) : nullptr;
   v.seg_base = v.flags ? v.tile_hist + 2 * (T ? T : 1) : nullptr;
-  v.zero_bytes = (4 + 3 * (T ? T : 1) + 1) * sizeof(uint32_t);
+  v.zero_bytes = nz * sizeof(uint32_t);
   if (total) *total = c.total();
   return v;
 }
@@ -203,6 +202,8 @@ struct FwdPreArgs {
   int P, D, M, W, H, tiles_x, tiles_y;
   uint32_t* tile_hist;  // [T] instance histogram (zeroed by the caller), or nullptr (legacy binning)
   uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
+  float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
+  size_t zero_f4;       // ... in float4 units
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int prefiltered, tight_bins;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;

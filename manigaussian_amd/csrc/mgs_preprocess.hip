@@ -113,6 +113,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   if (HIST && threadIdx.x == 0) s_total = 0;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int T = a.tiles_x * a.tiles_y;
+  if (a.zero_ptr) {  // fire-and-forget stores: they drain while the projection math runs
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)idx; i < a.zero_f4; i += (size_t)gridDim.x * blockDim.x) a.zero_ptr[i] = z;
+  }
   if constexpr (HIST) {
     for (int t = threadIdx.x; t < T; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
@@ -216,9 +220,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
           g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
         }
         g.depths[idx] = view_z;
-        g.means2D[idx] = make_float2(px, py);
-        g.conic_opacity[idx] = make_float4(conx, cony, conz, opacity);
-        g.cullext[idx] = make_float2(hx, hy);
+        g.rec[2 * (size_t)idx] = make_float4(px, py, conx, cony);
+        g.rec[2 * (size_t)idx + 1] = make_float4(conz, opacity, hx, hy);
         radius_out = (int32_t)my_radius;
         touched = (uint32_t)((y1 - y0) * (x1 - x0));
         rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;

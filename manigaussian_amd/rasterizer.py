@@ -67,10 +67,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                        s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
                        s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered, s.debug,
                        s.include_feature)
-        (num_rendered, color, language_feature, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
-            _C.rasterize_gaussians, native_args, s.debug, "snapshot_fw.dump", "forward")
+        # when a backward will follow, the forward also allocates its gradient buffer and zeroes the accumulator
+        # block inside the preprocess kernel (saves the backward a 17 MB fill on the critical path at C3)
+        want = any(ctx.needs_input_grad[:9])
+        (num_rendered, color, language_feature, radii, geomBuffer, binningBuffer, imgBuffer, grad_buffer) = _call_native(
+            _C._forward, native_args + (want,), s.debug, "snapshot_fw.dump", "forward")
+        ctx.grad_buffer = grad_buffer
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        ctx.mark_non_differentiable(radii)     # int32: no gradient, and no zeros_like(radii) fill per backward
+        ctx.set_materialize_grads(False)       # an unused output arrives as None instead of a zero tensor
         ctx.save_for_backward(colors_precomp, language_feature_precomp, means3D, scales, rotations, cov3Ds_precomp,
                               radii, sh, geomBuffer, binningBuffer, imgBuffer)
         return color, language_feature, radii
@@ -80,12 +86,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         (colors_precomp, language_feature_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None and grad_out_language_feature is None:
+            return (None,) * 10
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+        if grad_out_language_feature is None:
+            grad_out_language_feature = torch.zeros((language_feature_precomp.size(1) if s.include_feature else 1,
+                                                     s.image_height, s.image_width) if s.include_feature else (1,),
+                                                    dtype=torch.float32, device=means3D.device)
         native_args = (s.bg, means3D, radii, colors_precomp, language_feature_precomp, scales, rotations,
                        s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
                        grad_out_color, grad_out_language_feature, sh, s.sh_degree, s.campos, geomBuffer,
                        ctx.num_rendered, binningBuffer, imgBuffer, s.debug, s.include_feature)
+        grad_buffer, ctx.grad_buffer = ctx.grad_buffer, None  # pre-zeroed for ONE backward; a second one allocates + fills
         (g_means2D, g_colors, g_feature, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _call_native(
-            _C.rasterize_gaussians_backward, native_args, s.debug, "snapshot_bw.dump", "backward")
+            _C._backward, native_args + (grad_buffer,), s.debug, "snapshot_bw.dump", "backward")
         # order of forward's inputs (reference: __init__.py:151-162)
         return (g_means3D, g_means2D, g_sh, g_colors, g_feature, g_opacities, g_scales, g_rotations, g_cov3D, None)
 
