@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--tight-bins", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
+                                                      "the N>1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -97,11 +100,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     n_gpus = world
     if args.tight_bins is not None:
         _lib.set_option("tight_bins", args.tight_bins)
@@ -117,16 +125,28 @@ def main():
     settings = GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev))
     rast = GaussianRasterizer(settings)
     plist = list(params.values())
+    pending = []  # (work handle, gradients) of the all-reduce still in flight
+
+    def drain():
+        while pending:
+            h, _ = pending.pop()
+            if h is not None:
+                h.wait()
 
     def step():
         color, feat, radii = rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
                                   shs=params["shs"], language_feature_precomp=params["language_feature"],
                                   scales=params["scales"], rotations=params["rotations"])
         grads = torch.autograd.grad([color, feat], plist, [d_color, d_feat])
-        all_reduce_grads(grads)  # N > 1: ONE in-place all-reduce of the allocation all gradients alias
+        # N > 1: ONE in-place all-reduce of the allocation all gradients alias, asynchronous on RCCL's stream: it
+        # overlaps the next step's forward/backward (which write a fresh allocation); a step's reduced gradients are
+        # complete when the following step issues its own all-reduce (a trainer's optimizer would wait right there).
+        drain()
+        pending.append((all_reduce_grads(grads, async_op=True), grads))
         return grads
 
     def sync_all():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -158,6 +178,7 @@ def main():
     n_extra = min(args.steps, 20)
     for _ in range(n_extra):
         step()
+    drain()
     torch.cuda.synchronize()
     _lib.set_option("profile", 0)
     stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.profile_read(reset=True).items()}

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
     const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
     const unsigned long long smask = ballot(surv);
     // rows of the survivors -> LDS (the previous round's readers of this stage passed the round's last barrier)
-    if (surv) stage_row<F>(stage, lane, id, r.colors, use_feat ? r.feats : nullptr);
+    if (surv && !(r.dbg & 8)) stage_row<F>(stage, lane, id, r.colors, use_feat ? r.feats : nullptr);
     // ---- phase A: transmittance product of this chunk ----
     float tp = 1.0f;
     {
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
         const bool term = cand && (test_T < 0.0001f);
         done = done || term;
         const bool blend = cand && !term;
-        if (ballot(blend) == 0) continue;
+        if (ballot(blend) == 0 || (r.dbg & 1)) continue;
         const float wgt = blend ? alpha * T : 0.f;
         const float4* row = stage + j * ROW4;
         if constexpr (F > 0) {
@@ -333,8 +333,10 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
       T_end[slot * 64 + lane] = T;
       last_pos[slot * 64 + lane] = last;
       float* pp = partial + slot * NCH * 64 + lane;
+      if (!(r.dbg & 16)) {
 #pragma unroll
-      for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
+        for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
+      }
       if (live) { my_vis = c + 1; my_Tf = T; }
       wave_lds_sync();  // every lane is done reading the stage rows
 #pragma unroll
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
 #pragma unroll
     for (int k = 0; k < NOWN; k++) {
       const int ch = w + k * NW;
-      if (ch < NCH && (ch < 3 || use_feat)) {
+      if (ch < NCH && (ch < 3 || use_feat) && !(r.dbg & 64)) {
         float acc = img[k];
         for (int w2 = 0; w2 < NW; w2++)
           if (entered[w2]) acc += reinterpret_cast<const float*>(lds + w2 * STAGE4)[ch * 64 + lane];
@@ -597,7 +599,7 @@ static hipError_t fwd_F(const RenderArgs& r, const BinView& b, const ImgView& im
 #define MGS_CF64(FAST, EXACT)                                                                                       \
   hipLaunchKernelGGL((coop_fwd64_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges,          \
                      b.point_list, b.inst, cv.T_end, cv.last_pos, cv.partial, im.final_T, cv.last_chunk, oc, of)
-  if (cv.CH == 64 && r.dbg == 0 && options().fwd_mode == 1) {
+  if (cv.CH == 64 && options().fwd_mode == 1) {
     if (r.fast_exp) { if (r.exact_cull) MGS_CF64(true, true); else MGS_CF64(true, false); }
     else            { if (r.exact_cull) MGS_CF64(false, true); else MGS_CF64(false, false); }
   } else if (r.fast_exp) { if (r.exact_cull) MGS_CF(true, true); else MGS_CF(true, false); }

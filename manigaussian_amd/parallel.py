@@ -94,7 +94,7 @@ def all_reduce_grads(grads: Sequence[torch.Tensor], group=None, async_op: bool =
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     gs = [g for g in grads if g is not None]
     bucket = torch.cat([g.reshape(-1) for g in gs])
-    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)  # blocking: the scatter-back below needs the result
     off = 0
     for g in gs:
         g.copy_(bucket[off:off + g.numel()].view_as(g))
