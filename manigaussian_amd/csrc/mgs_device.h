@@ -127,25 +127,31 @@ template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ float dpp_keep(float old, float v) {  // lanes without a source keep `old`
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
 }
-// inclusive prefix sum over the lanes of each 32-lane half
+// inclusive prefix sum over the lanes of each 32-lane half (one v_add_f32_dpp per step, see the product scan below)
+#define MGS_SCAN_ADD_STEP(v, ctrl) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
 __device__ __forceinline__ float half_incl_scan_add(float v) {
-  v += dpp_keep<DPP_ROW_SHR1>(0.f, v);
-  v += dpp_keep<DPP_ROW_SHR2>(0.f, v);
-  v += dpp_keep<DPP_ROW_SHR4>(0.f, v);
-  v += dpp_keep<DPP_ROW_SHR8>(0.f, v);
-  v += dpp_keep<DPP_ROW_BCAST15, 0xA>(0.f, v);
+  MGS_SCAN_ADD_STEP(v, "row_shr:1 row_mask:0xf");
+  MGS_SCAN_ADD_STEP(v, "row_shr:2 row_mask:0xf");
+  MGS_SCAN_ADD_STEP(v, "row_shr:4 row_mask:0xf");
+  MGS_SCAN_ADD_STEP(v, "row_shr:8 row_mask:0xf");
+  MGS_SCAN_ADD_STEP(v, "row_bcast:15 row_mask:0xa");
   return v;
 }
 // exclusive prefix product over the lanes of each 32-lane half (lane 0 / 32 get 1)
+// The multiply steps are v_mul_f32_dpp with bound_ctrl:0: a lane whose DPP source is out of range is not written
+// and keeps its value -- exactly the scan's identity -- so a step is ONE instruction (the builtin route costs a
+// v_mov 1.0 + v_mov_dpp + v_mul per step).  hipcc pads nothing inside asm: the s_nop 1 covers the two wait states a
+// DPP read needs after the VALU write of its source.
+#define MGS_SCAN_MUL_STEP(v, ctrl) asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
 __device__ __forceinline__ float half_excl_scan_mul(float v, int lane) {
   float s = dpp_keep<DPP_ROW_SHR1>(1.f, v);                       // lane i <- v[i-1] inside a row
   const float prev_row_last = dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, v);  // rows 1,3 <- v[15], v[47]
   s = ((lane & 15) == 0 && (lane & 16)) ? prev_row_last : s;
-  s *= dpp_keep<DPP_ROW_SHR1>(1.f, s);
-  s *= dpp_keep<DPP_ROW_SHR2>(1.f, s);
-  s *= dpp_keep<DPP_ROW_SHR4>(1.f, s);
-  s *= dpp_keep<DPP_ROW_SHR8>(1.f, s);
-  s *= dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, s);
+  MGS_SCAN_MUL_STEP(s, "row_shr:1 row_mask:0xf");
+  MGS_SCAN_MUL_STEP(s, "row_shr:2 row_mask:0xf");
+  MGS_SCAN_MUL_STEP(s, "row_shr:4 row_mask:0xf");
+  MGS_SCAN_MUL_STEP(s, "row_shr:8 row_mask:0xf");
+  MGS_SCAN_MUL_STEP(s, "row_bcast:15 row_mask:0xa");
   return s;
 }
 // value of lane 31 (lanes 0..31) / lane 63 (lanes 32..63)
