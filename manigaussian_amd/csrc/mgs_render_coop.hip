@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
   __shared__ float Tp[NW][64];
   __shared__ float red_Tf[64];
   __shared__ uint32_t red_vis[64];
-  __shared__ uint32_t entered[NW];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
@@ -272,18 +271,21 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
     Tp[w][lane] = tp;
     __syncthreads();
     // ---- prefix in chunk order (identical arithmetic in every wave) ----
-    float T = Tround;
-    for (int w2 = 0; w2 < w; w2++) T *= Tp[w2][lane];
-    float Tnext = T;
-    for (int w2 = w; w2 < NW; w2++) Tnext *= Tp[w2][lane];
+    float T = Tround, Tnext = Tround;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) {  // all NW reads in flight; the multiplication order is the chunk order
+      const float t2 = Tp[w2][lane];
+      T = (w2 < w) ? T * t2 : T;
+      Tnext *= t2;
+    }
     // ---- phase B: blend this chunk ----
     const bool live = has && p.inside && !(T < 0.0001f);
     const bool enter = ballot(live) != 0;
+    float C[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) C[i] = 0.f;
     if (enter) {
       bool done = !live;
-      float C[NCH];
-#pragma unroll
-      for (int i = 0; i < NCH; i++) C[i] = 0.f;
       uint32_t last = 0;
       wave_lds_sync();  // this wave's stage rows are written
       unsigned long long mask = smask;
@@ -338,11 +340,10 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
         for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
       }
       if (live) { my_vis = c + 1; my_Tf = T; }
-      wave_lds_sync();  // every lane is done reading the stage rows
-#pragma unroll
-      for (int i = 0; i < NCH; i++) stage_f[i * 64 + lane] = C[i];
     }
-    if (lane == 0) entered[w] = enter ? 1u : 0u;
+    wave_lds_sync();  // every lane is done reading the stage rows
+#pragma unroll
+    for (int i = 0; i < NCH; i++) stage_f[i * 64 + lane] = C[i];  // zeros from a wave that had nothing to blend
     __syncthreads();
     // ---- image += this round's partial colours, in chunk order; wave w owns channels w, w + NW, ... ----
 #pragma unroll
@@ -350,8 +351,8 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
       const int ch = w + k * NW;
       if (ch < NCH && (ch < 3 || use_feat) && !(r.dbg & 64)) {
         float acc = img[k];
-        for (int w2 = 0; w2 < NW; w2++)
-          if (entered[w2]) acc += reinterpret_cast<const float*>(lds + w2 * STAGE4)[ch * 64 + lane];
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) acc += reinterpret_cast<const float*>(lds + w2 * STAGE4)[ch * 64 + lane];
         img[k] = acc;
       }
     }
