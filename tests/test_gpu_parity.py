@@ -73,6 +73,10 @@ CASES = {
     "f8": dict(P=2000, F=8), "f16": dict(P=2000, F=16), "f64": dict(P=1500, F=64),
     "image_256": dict(P=8000, F=32, W=256, H=256),
     "tiny_image_8x8": dict(P=500, F=3, W=8, H=8),
+    "single_gaussian": dict(P=1, F=3, W=16, H=16),
+    "odd_17x33_f64": dict(P=70, F=64, W=17, H=33),
+    "image_512_1024_tiles": dict(P=6000, F=8, W=512, H=512),
+    "image_1080p_legacy_binning_fallback": dict(P=3000, F=3, W=1920, H=1080),
     "other_view": dict(P=4000, F=3, cam_index=3),
 }
 
