@@ -78,14 +78,19 @@ def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefilt
 # {flags, num_rendered} through it) and the high-water mark of num_rendered per problem shape, which sizes
 # the binning workspace BEFORE the count is known (the reference sizes it after a blocking read-back).
 _DEV_STATE = {}
+_CAPACITY = {}  # device -> {shape key: capacity}; shared by all threads (a stale read only costs one retry)
 
 
 def _dev_state(dev):
-    st = _DEV_STATE.get(dev)
+    """The status word belongs to ONE in-flight forward: it is per (device, calling thread) -- ctypes drops the
+    GIL during the native call, so two Python threads can be inside mgs_rasterize_forward at once."""
+    import threading
+    key = (dev, threading.get_ident())
+    st = _DEV_STATE.get(key)
     if st is None:
         pin = torch.zeros(2, dtype=torch.int64).pin_memory()
-        st = {"status": pin, "status_ptr": pin.data_ptr(), "cap": {}}
-        _DEV_STATE[dev] = st
+        st = {"status": pin, "status_ptr": pin.data_ptr(), "cap": _CAPACITY.setdefault(dev, {})}
+        _DEV_STATE[key] = st
     return st
 
 
