@@ -227,6 +227,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
   im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
   FwdPreArgs p;
+  p.V = 1; p.Pg = a->P; p.Hp = 0;
   p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
   p.tiles_x = (a->W + TILE - 1) / TILE; p.tiles_y = (a->H + TILE - 1) / TILE;
   p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
@@ -299,7 +300,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
     StageTimer t(ST_SORT, stream);
-    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, cap, tiles_x, tiles_y, options().seg, host_status, stream),
+    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, tiles_x, tiles_y, options().seg, host_status, stream),
               "segment-sort binning", a->debug, stream);
   } else {
     { StageTimer t(ST_DUPLICATE, stream);
@@ -313,6 +314,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   RenderArgs r;
   r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
   r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
+  r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
@@ -490,6 +492,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     RenderArgs r;
     r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
     r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
+  r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
     r.bg = a->background;
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;

@@ -191,7 +191,7 @@ __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t
 
 // Workgroups [0, nblk) scatter the keys of PRE_BLOCK Gaussians each (the partition the preprocess used);
 // workgroup nblk publishes ranges and the segment table for the next two kernels.
-__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int P, int T, int tiles_x, int nblk, uint32_t seg,
+__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int tiles_x, int nblk, uint32_t seg,
                                                                 uint32_t capacity, const uint32_t* __restrict__ flags,
                                                                 uint64_t* host_status,
                                                                 const uint2* __restrict__ rect,
@@ -246,8 +246,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int P, int T, in
     if (tid == 0) seg_base[T] = total;
     return;
   }
-  const int idx = blockIdx.x * blockDim.x + tid;
-  if (idx >= P) return;
+  // same (view, Gaussian) partition as the forward preprocess: workgroups never straddle views
+  const int bpv = (Pg + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int v = (int)blockIdx.x / bpv;
+  const int gi = ((int)blockIdx.x - v * bpv) * PRE_BLOCK + tid;
+  if (gi >= Pg) return;
+  const int idx = v * Pg + gi;  // (virtual) instance owner
   const uint2 r = rect[idx];
   const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16);
   const int y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
@@ -428,14 +432,14 @@ static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView
                      b.keys, g.rec, b.point_list, b.inst);
 }
 
-hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int P, int capacity, int tiles_x,
-                              int tiles_y, int seg, uint64_t* host_status, hipStream_t s) {
+hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
+                              int tiles_x, int tiles_y, int seg, uint64_t* host_status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
-  if (P <= 0) return hipSuccess;
-  const int T = tiles_x * tiles_y;
-  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (Pg <= 0) return hipSuccess;
+  const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
+  const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
   // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, P, T,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
                      tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
                      im.ranges, im.seg_base, b.seg_desc);
   switch (seg) {

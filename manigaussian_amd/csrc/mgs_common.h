@@ -198,8 +198,16 @@ Options& options();
 // ---- launch wrappers (one per .hip translation unit) --------------------------------------------
 void set_error(const char* fmt, ...);
 
+constexpr int MAX_VIEWS = 16;
+struct ViewCam {  // per-view camera of a multi-view batch
+  float tanfovx, tanfovy, focal_x, focal_y;
+  const float *viewmatrix, *projmatrix, *campos;
+};
+
 struct FwdPreArgs {
   int P, D, M, W, H, tiles_x, tiles_y;
+  int V, Pg, Hp;             // V > 1: P = V * Pg virtual Gaussians, H = view height, tiles_y = tile rows of ONE view
+  ViewCam cam[MAX_VIEWS];    // V > 1 only
   uint32_t* tile_hist;  // [T] instance histogram (zeroed by the caller), or nullptr (legacy binning)
   uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
@@ -212,8 +220,8 @@ struct FwdPreArgs {
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s);
 hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
 // bin_mode 1: scatter -> segment sort -> rank merge + emit (hist is the host copy of im.tile_hist)
-hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int P, int capacity, int tiles_x,
-                              int tiles_y, int seg, uint64_t* host_status, hipStream_t s);
+hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
+                              int tiles_x, int tiles_y, int seg, uint64_t* host_status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
                             int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);
 hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s);
@@ -223,6 +231,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, c
 
 struct RenderArgs {
   int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, bwd_reduce, exact_cull;
+  // Multi-view batches render into an ATLAS: V views stacked vertically, each padded to Hp = tiles_y_view * 16 rows, so
+  // that binning and compositing see one image of H = V * Hp rows (V == 1: H is the image height, Hv == H).
+  // Instance ids are then "virtual": id = view * Pg + Gaussian.
+  int V, Pg, Hv, Hp;
+  int colors_per_view;  // 1: `colors` is indexed by the virtual id (SH colours, per view), 0: by the Gaussian
   int dbg;  // timing experiments only (results invalid when non-zero): bit0 skip blend, bit1 skip phase A, bit2 skip final sum, bit3 skip row staging
   const float* bg;
   const float* colors;   // [P,3] colors_precomp or geom.rgb
@@ -252,6 +265,8 @@ hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const Img
 
 struct BwdPreArgs {
   int P, D, M, W, H;
+  int V;                     // views; P = Gaussians (not virtual); radii, clamped, acc8, dL_dcolor, dL_dmeans2D, dL_dconic
+  ViewCam cam[MAX_VIEWS];    // are [V][P][.] when V > 1 and cam[v] replaces the single-view camera fields below
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   const float *means3D, *shs, *scales, *rotations, *cov3D, *viewmatrix, *projmatrix, *campos;
   const int32_t* radii;

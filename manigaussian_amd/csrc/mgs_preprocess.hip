@@ -111,12 +111,21 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   extern __shared__ uint32_t s_hist[];  // [tiles_x * tiles_y] when HIST
   __shared__ uint32_t s_total;
   if (HIST && threadIdx.x == 0) s_total = 0;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int T = a.tiles_x * a.tiles_y;
+  // Workgroups never straddle views: view = blockIdx / (workgroups per view), so the camera is wave-uniform.
+  // Single view (V == 1): gi == idx and everything below is the plain per-Gaussian preprocess.
+  const int bpv = (a.Pg + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int v = (int)blockIdx.x / bpv;
+  const int gi = ((int)blockIdx.x - v * bpv) * (int)blockDim.x + (int)threadIdx.x;  // Gaussian
+  const int idx = v * a.Pg + gi;                                                    // (virtual) instance owner
+  const int Tv = a.tiles_x * a.tiles_y, T = Tv * a.V;
   if (a.zero_ptr) {  // fire-and-forget stores: they drain while the projection math runs
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)idx; i < a.zero_f4; i += (size_t)gridDim.x * blockDim.x) a.zero_ptr[i] = z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)gridDim.x * blockDim.x)
+      a.zero_ptr[i] = z;
   }
+  const bool batch = a.V > 1;
+  const float tanfovx = batch ? a.cam[v].tanfovx : a.tanfovx, tanfovy = batch ? a.cam[v].tanfovy : a.tanfovy;
+  const float focal_x = batch ? a.cam[v].focal_x : a.focal_x, focal_y = batch ? a.cam[v].focal_y : a.focal_y;
   if constexpr (HIST) {
     for (int t = threadIdx.x; t < T; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
@@ -124,10 +133,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   int32_t radius_out = 0;
   uint32_t touched = 0;
   int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
-  if (idx < a.P) {
-  const float* __restrict__ vm = a.viewmatrix;
-  const float* __restrict__ pm = a.projmatrix;
-  const V3 p = ld3(a.means3D, idx);
+  if (gi < a.Pg) {
+  const float* __restrict__ vm = batch ? a.cam[v].viewmatrix : a.viewmatrix;
+  const float* __restrict__ pm = batch ? a.cam[v].projmatrix : a.projmatrix;
+  const float* __restrict__ campos = batch ? a.cam[v].campos : a.campos;
+  const V3 p = ld3(a.means3D, gi);
   const float view_z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
   if (view_z <= 0.2f) {  // auxiliary.h:154 near cull
     if (a.prefiltered) atomicOr(&g.flags[0], 1u);
@@ -139,11 +149,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     float c6[6];
     if (a.cov3D_precomp) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) c6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+      for (int i = 0; i < 6; i++) c6[i] = a.cov3D_precomp[6 * (size_t)gi + i];
     } else {
       float R[3][3];
-      quat_rows(a.rotations + 4 * (size_t)idx, R);
-      const V3 s = ld3(a.scales, idx);
+      quat_rows(a.rotations + 4 * (size_t)gi, R);
+      const V3 s = ld3(a.scales, gi);
       const float sc[3] = {a.scale_modifier * s.x, a.scale_modifier * s.y, a.scale_modifier * s.z};
       float m[3][3];
 #pragma unroll
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
 #pragma unroll
       for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c6[i];
     }
-    const ViewCov vc = view_cov(p, vm, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy);
+    const ViewCov vc = view_cov(p, vm, focal_x, focal_y, tanfovx, tanfovy);
     float c00, c01, c11, Va[3], Vb[3];
     cov2d_from(vc, c6, c00, c01, c11, Va, Vb);
     c00 += 0.3f;
@@ -175,7 +185,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       int x0, y0, x1, y1;
       get_rect(px, py, (int)my_radius, a.tiles_x, a.tiles_y, x0, y0, x1, y1);
       if ((x1 - x0) * (y1 - y0) != 0) {
-        const float opacity = a.opacities[idx];
+        const float opacity = a.opacities[gi];
         // bbox of {alpha >= 1/255} = {q(d) <= 2 ln(255 o)}: half extents sqrt(tau * cov_xx), sqrt(tau * cov_yy)
         // (cov = conic^-1 = the low-passed cov2D).  Inflated so it is conservative w.r.t. float rounding
         // of the per-pixel test; the per-pixel test itself stays exact.
@@ -189,11 +199,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
         if (a.tight_bins) tight_rect(px, py, hx, hy, x0, y0, x1, y1);
         if (a.colors_precomp == nullptr) {
           // forward.cu:21-72
-          const V3 cam = {a.campos[0], a.campos[1], a.campos[2]};
+          const V3 cam = {campos[0], campos[1], campos[2]};
           V3 dir = p - cam;
           const float len = sqrtf(dot(dir, dir));
           dir = {dir.x / len, dir.y / len, dir.z / len};
-          const float* __restrict__ sh = a.shs + (size_t)idx * a.M * 3;
+          const float* __restrict__ sh = a.shs + (size_t)gi * a.M * 3;
           auto SH = [&](int k) { return v3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
           V3 res = SH_C0 * SH(0);
           if (a.D > 0) {
@@ -220,11 +230,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
           g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
         }
         g.depths[idx] = view_z;
-        g.rec[2 * (size_t)idx] = make_float4(px, py, conx, cony);
+        g.rec[2 * (size_t)idx] = make_float4(px, py + (float)(v * a.Hp), conx, cony);  // atlas row of the view
         g.rec[2 * (size_t)idx + 1] = make_float4(conz, opacity, hx, hy);
         radius_out = (int32_t)my_radius;
         touched = (uint32_t)((y1 - y0) * (x1 - x0));
-        rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;
+        rx0 = x0; ry0 = y0 + v * a.tiles_y; rx1 = x1; ry1 = y1 + v * a.tiles_y;  // atlas tile rows of the view
       }
     }
   }
@@ -252,10 +262,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   if (a.tile_hist)
-    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((a.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK),
-                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y, s, a, g, radii);
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK)), dim3(PRE_BLOCK),
+                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, a, g, radii);
   else
-    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, g, radii);
+    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.Pg + 255) / 256), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();
 }
 

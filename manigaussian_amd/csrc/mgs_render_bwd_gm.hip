@@ -73,12 +73,12 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   const PixBlk p = pix_blk(r, tile, sub, lane);
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
-  const size_t HW = (size_t)r.H * r.W;
-  const size_t pix = (size_t)p.py * r.W + p.px;
+  const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
+  const size_t pix = p.pixl;
   const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
 
   // ---- pixel-lane prologue: dL of this block into LDS (both layouts), q[c] = dL . partial[c] ----
-  const float T_final = any ? final_T[pix] : 0.f;
+  const float T_final = any ? final_T[p.pixa] : 0.f;
   float bgT = 0.f;
   {
     float dLc[3] = {0.f, 0.f, 0.f};
@@ -87,11 +87,11 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
     for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
     if (any) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[ch * HW + pix];
+      for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[((size_t)p.v * 3 + ch) * HW + pix];
       if constexpr (F > 0) {
         if (use_feat) {
 #pragma unroll
-          for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[ch * HW + pix];
+          for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[((size_t)p.v * F + ch) * HW + pix];
         }
       }
     }
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   }
   __syncthreads();  // dLT/dLs (LDS) and q (global, this workgroup only) are visible to every wave
 
-  const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.H;
+  const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
   const int n = lane & 31, h = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
 
@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       const float ex = rec.g0.x, ey = rec.g0.y, cx = rec.g0.z, cy = rec.g0.w, cz = rec.g1.x;
       const float op = has ? rec.g1.y : 0.f;
       const uint32_t pos = has ? rec.pos : 0xffffffffu;
-      const uint32_t id = rec.id;
+      const uint32_t id = rec.id;                 // instance id (virtual in a multi-view batch): acc8 / per-view colour row
+      const uint32_t gidn = gauss_of(r, id);      // the Gaussian: feature row, feature gradient
+      const uint32_t cid = r.colors_per_view ? id : gidn;
 
       if (g == 1) {
         // group 1 starts from T_in * prod over group 0 of (1 - alpha): a light pass over group 0's entries
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
 #pragma unroll
           for (int t = 0; t < KCH / 2; t++) {
             const int c = 2 * t + h;
-            const float* src = (c < F && use_feat) ? r.feats + (size_t)id * F + c : r.colors + (size_t)id * 3 + (c - F);
+            const float* src = (c < F && use_feat) ? r.feats + (size_t)gidn * F + c : r.colors + (size_t)cid * 3 + (c - F);
             const bool okc = has && ((c < F) ? use_feat : (c < F + 3));
             bop[t] = okc ? *src : 0.f;
           }
@@ -307,7 +309,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
             for (int k = 0; k < 16 * NCT; k++) {  // instruction k: Gaussians 2k', 2k'+1 of the tile half, 32 channels each
               const int gg = 2 * (k % 16) + h, ch = 32 * (k / 16) + n;
               const uint32_t gi2 = gid[w][gg];
-              if (gi2 != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gi2 * F + ch, tr[gg * TROW + ch]);
+              if (gi2 != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gauss_of(r, gi2) * F + ch, tr[gg * TROW + ch]);
             }
           }
         }
@@ -322,7 +324,8 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
           const int gg = 16 * k + (lane >> 2), i = lane & 3;
           const uint32_t gi2 = gid[w][gg];
           if (gi2 != 0xffffffffu && i < 3)
-            unsafeAtomicAdd(dL_dcolors + (size_t)gi2 * 3 + i, tr[gg * TROW + NCT * 32 + 6 + i]);
+            unsafeAtomicAdd(dL_dcolors + (size_t)(r.colors_per_view ? gi2 : gauss_of(r, gi2)) * 3 + i,
+                            tr[gg * TROW + NCT * 32 + 6 + i]);
         }
         wave_lds_sync();  // tr / gid are rewritten by the next group
       }

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64) chunk_blend_kernel(RenderArgs r, int CH, c
     unsigned long long mask = ballot(surv);
     if (mask == 0) continue;
     __syncthreads();
-    if (surv) stage_row<F>(stage, lane, point_list[e], r.colors, use_feat ? r.feats : nullptr);
+    if (surv) stage_row<F>(stage, lane, point_list[e], point_list[e], r.colors, use_feat ? r.feats : nullptr);
     __syncthreads();
     while (mask) {
       const int j = __builtin_ctzll(mask);
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64) chunk_bwd_kernel(RenderArgs r, int CH, con
     __syncthreads();
     if (surv) {
       id_l = point_list[e];
-      stage_row<F>(stage, lane, id_l, r.colors, use_feat ? r.feats : nullptr);
+      stage_row<F>(stage, lane, id_l, id_l, r.colors, use_feat ? r.feats : nullptr);
     }
     __syncthreads();
     while (mask) {

@@ -25,8 +25,8 @@ __device__ __forceinline__ void map_block(int b, int& tile, int& sub) {
 }
 
 template <int F>
-__device__ __forceinline__ void stage_row(float4* stage, int lane, uint32_t id, const float* __restrict__ colors,
-                                          const float* __restrict__ feats) {
+__device__ __forceinline__ void stage_row(float4* stage, int lane, uint32_t id, uint32_t cid,
+                                          const float* __restrict__ colors, const float* __restrict__ feats) {
   constexpr int ROW4 = Row<F>::ROW4;
   float tmp[ROW4 * 4];
 #pragma unroll
@@ -46,9 +46,9 @@ __device__ __forceinline__ void stage_row(float4* stage, int lane, uint32_t id, 
       }
     }
   }
-  tmp[F] = colors[(size_t)id * 3];
-  tmp[F + 1] = colors[(size_t)id * 3 + 1];
-  tmp[F + 2] = colors[(size_t)id * 3 + 2];
+  tmp[F] = colors[(size_t)cid * 3];      // id: Gaussian (feature row); cid: colour row (per view when it comes from SH)
+  tmp[F + 1] = colors[(size_t)cid * 3 + 1];
+  tmp[F + 2] = colors[(size_t)cid * 3 + 2];
 #pragma unroll
   for (int i = 0; i < ROW4; i++)
     stage[lane * ROW4 + i] = make_float4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
@@ -95,9 +95,12 @@ __device__ __forceinline__ bool reaches_block(const float4& g0, const float4& g1
 }
 
 struct PixBlk {
-  int px, py;
+  int px, py;      // pixel of this lane in ATLAS coordinates (== image coordinates for a single view)
+  int v;           // view of the block
   bool inside;
   float pxf, pyf, bxmin, bxmax, bymin, bymax;
+  size_t pixl;     // y_local * W + x inside the view's image plane
+  size_t pixa;     // atlas pixel index py * W + px (per-pixel workspace state)
 };
 __device__ __forceinline__ PixBlk pix_blk(const RenderArgs& r, int tile, int sub, int lane) {
   PixBlk p;
@@ -105,11 +108,20 @@ __device__ __forceinline__ PixBlk pix_blk(const RenderArgs& r, int tile, int sub
   const int bx0 = tx * TILE + (sub & 1) * SUB, by0 = ty * TILE + (sub >> 1) * SUB;
   p.px = bx0 + (lane & 7);
   p.py = by0 + (lane >> 3);
-  p.inside = p.px < r.W && p.py < r.H;
+  int yl = p.py;
+  p.v = 0;
+  if (r.V > 1) { p.v = p.py / r.Hp; yl = p.py - p.v * r.Hp; }
+  p.inside = p.px < r.W && yl < r.Hv;
   p.pxf = (float)p.px; p.pyf = (float)p.py;
   p.bxmin = (float)bx0; p.bxmax = (float)min(bx0 + SUB - 1, r.W - 1);
   p.bymin = (float)by0; p.bymax = (float)min(by0 + SUB - 1, r.H - 1);
+  p.pixl = (size_t)yl * r.W + p.px;
+  p.pixa = (size_t)p.py * r.W + p.px;
   return p;
+}
+// Gaussian of a (possibly virtual) instance id
+__device__ __forceinline__ uint32_t gauss_of(const RenderArgs& r, uint32_t id) {
+  return r.V > 1 ? id % (uint32_t)r.Pg : id;
 }
 
 template <bool EXACT>

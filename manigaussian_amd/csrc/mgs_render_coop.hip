@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
         unsigned long long mask = ballot(surv);
         if (mask == 0) continue;
         wave_lds_sync();
-        if (surv && !(r.dbg & 8)) stage_row<F>(stage, lane, point_list[e], r.colors, use_feat ? r.feats : nullptr);
+        if (surv && !(r.dbg & 8)) stage_row<F>(stage, lane, point_list[e], point_list[e], r.colors, use_feat ? r.feats : nullptr);
         wave_lds_sync();
         while (mask) {
           const int j = __builtin_ctzll(mask);
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd_kernel(RenderArgs r, int CH,
   const float Tf = red_Tf[lane];
   const uint32_t vismax = wave_umax(vis);
   const size_t HW = (size_t)r.H * r.W;
-  const size_t pix = (size_t)p.py * r.W + p.px;
+  const size_t pix = p.pixa;
   for (int ch = w; ch < NCH; ch += NW) {
     if (ch >= 3 && !use_feat) break;
     float sum = 0.f;
@@ -250,7 +250,10 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
     const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
     const unsigned long long smask = ballot(surv);
     // rows of the survivors -> LDS (the previous round's readers of this stage passed the round's last barrier)
-    if (surv && !(r.dbg & 8)) stage_row<F>(stage, lane, id, r.colors, use_feat ? r.feats : nullptr);
+    if (surv && !(r.dbg & 8)) {
+      const uint32_t gid = gauss_of(r, id);
+      stage_row<F>(stage, lane, gid, r.colors_per_view ? id : gid, r.colors, use_feat ? r.feats : nullptr);
+    }
     // ---- phase A: transmittance product of this chunk ----
     float tp = 1.0f;
     {
@@ -369,19 +372,18 @@ __global__ void __launch_bounds__(NW * 64) coop_fwd64_kernel(RenderArgs r, const
   if (my_vis > 0 && my_vis == vis) red_Tf[lane] = my_Tf;  // exactly one wave owns the last visited chunk
   __syncthreads();
   const float Tf = red_Tf[lane];
-  const size_t HW = (size_t)r.H * r.W;
-  const size_t pix = (size_t)p.py * r.W + p.px;
+  const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
   if (p.inside) {
 #pragma unroll
     for (int k = 0; k < NOWN; k++) {
       const int ch = w + k * NW;
-      if (ch < 3) out_color[ch * HW + pix] = img[k] + Tf * r.bg[ch];
-      else if (ch < NCH && use_feat) out_feat[(ch - 3) * HW + pix] = img[k];
+      if (ch < 3) out_color[((size_t)p.v * 3 + ch) * HW + p.pixl] = img[k] + Tf * r.bg[ch];
+      else if (ch < NCH && use_feat) out_feat[((size_t)p.v * F + (ch - 3)) * HW + p.pixl] = img[k];
     }
   }
   if (w == 0) {
     last_chunk[((size_t)tile * 4 + sub) * 64 + lane] = vis;
-    if (p.inside) final_T[pix] = Tf;
+    if (p.inside) final_T[p.pixa] = Tf;
   }
 }
 
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(NW * 64) coop_bwd_kernel(RenderArgs r, int CH,
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
   const size_t HW = (size_t)r.H * r.W;
-  const size_t pix = (size_t)p.py * r.W + p.px;
+  const size_t pix = p.pixa;
   float4* stage = lds + w * 64 * ROW4;
   const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
 
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(NW * 64) coop_bwd_kernel(RenderArgs r, int CH,
       wave_lds_sync();
       if (surv) {
         id_l = point_list[e];
-        stage_row<F>(stage, lane, id_l, r.colors, use_feat ? r.feats : nullptr);
+        stage_row<F>(stage, lane, id_l, id_l, r.colors, use_feat ? r.feats : nullptr);
       }
       wave_lds_sync();
       while (mask) {

