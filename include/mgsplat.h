@@ -142,6 +142,30 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const i
                            float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                            float* dL_drotations, void* scratch, size_t scratch_bytes, mgs_stream_t stream);
 
+/* ---- multi-view batches: V views of one Gaussian set in one call (the reference renders one view per
+ * call, MG/neural_rendering.py:386 `assert bs == 1`).  MgsRasterArgs carries everything shared (its viewmatrix / projmatrix /
+ * campos / tanfov fields are ignored); images are [V,3,H,W] / [V,F,H,W]; radii, dL_dmeans2D, dL_dconic are [V,P,.];
+ * dL_dcolors is [V,P,3] with SH colours (colours differ per view) and [P,3] with colors_precomp; every other gradient is
+ * per Gaussian, summed over the views on the device.  Workspaces are sized by the mgs_views_*_bytes functions.
+ * host_status is required (see mgs_rasterize_forward).  Needs the default kernels and V * tiles <= 4096, V <= 16. */
+typedef struct MgsView {
+  float tanfovx, tanfovy;
+  const float* viewmatrix;  /* [16] */
+  const float* projmatrix;  /* [16] */
+  const float* campos;      /* [3]  */
+} MgsView;
+size_t mgs_views_geom_bytes(int P, int M, int W, int H, int V);
+size_t mgs_views_img_bytes(int W, int H, int V);
+size_t mgs_views_binning_bytes(int R, int W, int H, int F, int V);
+size_t mgs_views_backward_scratch_bytes(int P, int M, int F, int V);
+int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t* radii, float* out_color,
+                                float* out_feature, int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream);
+int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t num_rendered,
+                                 const int32_t* radii, const float* dL_dout_color, const float* dL_dout_feature,
+                                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                                 float* dL_dfeature, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                                 float* dL_drotations, void* scratch, size_t scratch_bytes, mgs_stream_t stream);
+
 /* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153).  present: uint8 [P] (torch.bool). */
 int mgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, mgs_stream_t stream);

@@ -5,5 +5,6 @@ reference's GaussianRasterizer / GaussianRasterizationSettings API, and the defo
 apply.  Native code: manigaussian_amd/csrc (HIP) -> libmgsplat.so, C ABI in include/mgsplat.h.
 """
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians  # noqa: F401
+from .views import GaussianRasterizerBatch  # noqa: F401
 
 __version__ = "0.1.0"

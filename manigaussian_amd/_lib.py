@@ -36,6 +36,13 @@ class MgsRasterArgs(ctypes.Structure):
     ]
 
 
+class MgsView(ctypes.Structure):
+    _fields_ = [("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("viewmatrix", c_fp), ("projmatrix", c_fp),
+                ("campos", c_fp)]
+
+
+MAX_VIEWS = 16
+
 _EXPORTS = {
     # name: (restype, argtypes)
     "mgs_abi_version": (ctypes.c_int, []),
@@ -53,6 +60,14 @@ _EXPORTS = {
                                              c_fp, c_fp]),
     "mgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp] + [c_fp] * 12 +
                                [c_fp, c_sz, c_fp]),
+    "mgs_views_geom_bytes": (c_sz, [ctypes.c_int] * 5),
+    "mgs_views_img_bytes": (c_sz, [ctypes.c_int] * 3),
+    "mgs_views_binning_bytes": (c_sz, [ctypes.c_int] * 5),
+    "mgs_views_backward_scratch_bytes": (c_sz, [ctypes.c_int] * 4),
+    "mgs_rasterize_forward_views": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(MgsView), c_fp,
+                                                   c_fp, c_fp, ctypes.POINTER(c_i32), c_fp, c_fp]),
+    "mgs_rasterize_backward_views": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(MgsView), c_i32,
+                                                    c_fp] + [c_fp] * 12 + [c_fp, c_sz, c_fp]),
     "mgs_mark_visible": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "mgs_deform_assemble_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [c_fp] * 10 + [c_fp]),
     "mgs_deform_assemble_backward": (ctypes.c_int, [ctypes.c_int] * 5 + [c_fp] * 3 + [c_fp]),

@@ -187,6 +187,7 @@ size_t mgs_binning_bytes(int R, int W, int H, int F) {
 }
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
 
+static const uint64_t kStatusPending = ~0ull;
 static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy);
 // Largest instance capacity whose binning layout fits `bytes`: the layout of a binning workspace is a function
 // of its SIZE, so forward and backward agree on it whatever count the caller passes.
@@ -211,7 +212,6 @@ static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy) {
   return lo;
 }
 
-static const uint64_t kStatusPending = ~0ull;
 
 // Everything of the forward before the instance count is known: zero tables, preprocess (+ legacy scan).
 static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_t stream, GeomView& g, ImgView& im,
@@ -227,7 +227,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
   im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
   FwdPreArgs p;
-  p.V = 1; p.Pg = a->P; p.Hp = 0;
+  p.V = 1; p.Pg = a->P; p.Hp = 0; p.use_cam = 0;
   p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
   p.tiles_x = (a->W + TILE - 1) / TILE; p.tiles_y = (a->H + TILE - 1) / TILE;
   p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
@@ -268,6 +268,27 @@ static int read_count_blocking(const GeomView& g, int P, bool segsort, hipStream
   MGS_HIP(hipMemcpyAsync(&host[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "flag read-back");
   MGS_HIP(hipStreamSynchronize(stream), "stream sync");
   *R = host[0]; *fl = host[1];
+  return MGS_OK;
+}
+
+// Wait for {flags, R} on the pinned status word (written by the binning kernel right after the preprocess).
+static int wait_status(uint64_t* host_status, hipStream_t stream, uint32_t* R, uint32_t* fl) {
+  volatile uint64_t* hs = host_status;
+  uint64_t st = *hs;
+  for (uint64_t spins = 0; st == kStatusPending; spins++) {
+    if ((spins & 0x3ff) == 0x3ff) {  // every ~1k polls: has the stream died or finished without reporting?
+      hipError_t q = hipStreamQuery(stream);
+      if (q != hipErrorNotReady) {
+        st = *hs;
+        if (st != kStatusPending) break;
+        set_error("forward finished without reporting the instance count: %s", hipGetErrorString(q));
+        return MGS_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+    st = *hs;
+  }
+  *R = (uint32_t)st; *fl = (uint32_t)(st >> 32);
   return MGS_OK;
 }
 
@@ -415,21 +436,8 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   *hs = kStatusPending;
   rc = enqueue_render(a, -1, radii, out_color, out_feature, host_status, stream);
   if (rc) return rc;
-  uint64_t st = *hs;
-  for (uint64_t spins = 0; st == kStatusPending; spins++) {
-    if ((spins & 0x3ff) == 0x3ff) {  // every ~1k polls: has the stream died or finished without reporting?
-      hipError_t q = hipStreamQuery(stream);
-      if (q != hipErrorNotReady) {
-        st = *hs;
-        if (st != kStatusPending) break;
-        set_error("forward finished without reporting the instance count: %s", hipGetErrorString(q));
-        return MGS_ERR_HIP;
-      }
-    }
-    __builtin_ia32_pause();
-    st = *hs;
-  }
-  R = (uint32_t)st; fl = (uint32_t)(st >> 32);
+  rc = wait_status(host_status, stream, &R, &fl);
+  if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
   *num_rendered = (int32_t)R;
@@ -511,6 +519,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
                 "render backward", a->debug, stream);
   }
   BwdPreArgs p;
+  p.V = 1; p.cov3D_per_view = 0; p.use_cam = 0;
   p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
   p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy;
   p.focal_y = a->H / (2.0f * a->tanfovy);
@@ -524,6 +533,203 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh; p.dL_dscales = dL_dscales; p.dL_drot = dL_drotations;
   { StageTimer t(ST_PREPROCESS_BWD, stream);
     MGS_STAGE(launch_preprocess_bwd(p, stream), "preprocess backward", a->debug, stream); }
+  return MGS_OK;
+}
+
+
+// ================================ multi-view batches ================================
+// V views of ONE Gaussian set in one call.  The views are stacked into an atlas (each padded to whole tile rows), every
+// (view, Gaussian) pair is a "virtual Gaussian" with id = view * P + Gaussian, and the binning and compositing kernels
+// run unchanged on the atlas: V x the workgroups per launch, one set of launches per batch.  Per-Gaussian gradients
+// are summed over the views on the device (atomics for colour/feature rows, registers in the backward preprocess).
+namespace mgs {
+struct Atlas { int V, tiles_x, tiles_yv, Hp, H, T; };
+static Atlas atlas_of(int W, int H, int V) {
+  Atlas at;
+  at.V = V; at.tiles_x = (W + TILE - 1) / TILE; at.tiles_yv = (H + TILE - 1) / TILE;
+  at.Hp = at.tiles_yv * TILE; at.H = V * at.Hp; at.T = at.tiles_x * at.tiles_yv * V;
+  return at;
+}
+static int check_views(const MgsRasterArgs* a, int V, const MgsView* views, MgsRasterArgs* a1) {
+  if (!a || !views || V < 1 || V > MAX_VIEWS) { set_error("views: need 1 <= V <= %d", MAX_VIEWS); return MGS_ERR_INVALID_ARG; }
+  *a1 = *a;
+  a1->viewmatrix = views[0].viewmatrix; a1->projmatrix = views[0].projmatrix; a1->campos = views[0].campos;
+  a1->tanfovx = views[0].tanfovx; a1->tanfovy = views[0].tanfovy;
+  int rc = check_common(a1);
+  if (rc) return rc;
+  for (int v = 0; v < V; v++)
+    if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].campos) { set_error("view %d: NULL matrix", v); return MGS_ERR_INVALID_ARG; }
+  const Options& o = options();
+  const Atlas at = atlas_of(a->W, a->H, V);
+  if (o.render_mode != 2 || chunk_size() != 64 || o.fwd_mode != 1 || o.bwd_mode != 1 || !segsort_binning(at.T) || a->debug) {
+    set_error("multi-view batches need the default kernels (render_mode 2, chunk 64, fwd_mode 1, bwd_mode 1, bin_mode 1, "
+              "debug 0) and V * tiles <= %d (got %d)", LDS_TILES, at.T);
+    return MGS_ERR_INVALID_ARG;
+  }
+  return MGS_OK;
+}
+static void fill_cams(ViewCam* cam, const MgsRasterArgs* a, int V, const MgsView* views) {
+  for (int v = 0; v < V; v++) {
+    cam[v].tanfovx = views[v].tanfovx; cam[v].tanfovy = views[v].tanfovy;
+    cam[v].focal_y = a->H / (2.0f * views[v].tanfovy);
+    cam[v].focal_x = a->W / (2.0f * views[v].tanfovx);
+    cam[v].viewmatrix = views[v].viewmatrix; cam[v].projmatrix = views[v].projmatrix; cam[v].campos = views[v].campos;
+  }
+}
+static RenderArgs views_render_args(const MgsRasterArgs* a, const Atlas& at, const GeomView& g) {
+  RenderArgs r;
+  const int F = a->include_feature ? a->F : 0;
+  r.W = a->W; r.H = at.H; r.tiles_x = at.tiles_x; r.tiles_y = at.tiles_yv * at.V; r.F = F; r.include_feature = F > 0;
+  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = 0;
+  r.V = at.V; r.Pg = a->P; r.Hv = a->H; r.Hp = at.Hp;
+  r.colors_per_view = a->colors_precomp ? 0 : 1;
+  r.bg = a->background;
+  r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
+  r.feats = a->language_feature;
+  return r;
+}
+}  // namespace mgs
+
+size_t mgs_views_geom_bytes(int P, int M, int W, int H, int V) {
+  const Atlas at = atlas_of(W, H, V > 0 ? V : 1);
+  size_t t; carve_geom(nullptr, P * at.V, M, at.T, &t); return t;
+}
+size_t mgs_views_img_bytes(int W, int H, int V) { const Atlas at = atlas_of(W, H, V > 0 ? V : 1); return mgs_img_bytes(W, at.H); }
+size_t mgs_views_binning_bytes(int R, int W, int H, int F, int V) {
+  const Atlas at = atlas_of(W, H, V > 0 ? V : 1);
+  return mgs_binning_bytes(R, W, at.H, F);
+}
+size_t mgs_views_backward_scratch_bytes(int P, int M, int F, int V) { return mgs_backward_scratch_bytes(P * (V > 0 ? V : 1), M, F); }
+
+int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t* radii, float* out_color,
+                                float* out_feature, int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MgsRasterArgs a1;
+  int rc = check_views(a, V, views, &a1);
+  if (rc) return rc;
+  if (!num_rendered || !host_status) { set_error("num_rendered / host_status is NULL"); return MGS_ERR_INVALID_ARG; }
+  *num_rendered = 0;
+  const size_t N = (size_t)a->W * a->H;
+  const int F = a->include_feature ? a->F : 0;
+  if (!out_color || (F > 0 && !out_feature)) { set_error("output image is NULL"); return MGS_ERR_INVALID_ARG; }
+  if (a->P == 0) {
+    MGS_HIP(hipMemsetAsync(out_color, 0, (size_t)V * 3 * N * sizeof(float), stream), "memset out_color");
+    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, (size_t)V * F * N * sizeof(float), stream), "memset out_feature");
+    return MGS_OK;
+  }
+  if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
+  const Atlas at = atlas_of(a->W, a->H, V);
+  if (!a->geom || a->geom_bytes < mgs_views_geom_bytes(a->P, a->M, a->W, a->H, V) || !a->img ||
+      a->img_bytes < mgs_views_img_bytes(a->W, a->H, V) || !a->binning) {
+    set_error("views: geom/img/binning workspace missing or too small");
+    return MGS_ERR_WORKSPACE;
+  }
+  const int cap = binning_capacity(a->binning_bytes, at.T, F, false);
+  if (cap < 0) { set_error("binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  GeomView g = carve_geom(a->geom, a->P * V, a->M, at.T, nullptr);
+  ImgView im = carve_img(a->img, a->W, at.H, nullptr);
+  g.flags = im.flags;
+  ChunkView cv;
+  BinView b = carve_binning(a->binning, cap, at.T, F, 64, false, &cv, nullptr);
+  FwdPreArgs p;
+  p.V = V; p.Pg = a->P; p.Hp = at.Hp; p.use_cam = 1;
+  p.P = a->P * V; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
+  p.tiles_x = at.tiles_x; p.tiles_y = at.tiles_yv;
+  p.tanfovx = p.tanfovy = p.focal_x = p.focal_y = 0.f;
+  p.scale_modifier = a->scale_modifier;
+  p.prefiltered = a->prefiltered; p.tight_bins = options().tight_bins;
+  p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
+  p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
+  p.viewmatrix = p.projmatrix = p.campos = nullptr;
+  fill_cams(p.cam, a, V, views);
+  p.zero_ptr = nullptr; p.zero_f4 = 0;
+  if (a->bwd_accum) {
+    if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
+      set_error("bwd_accum must be 16-byte aligned and a multiple of 16 bytes");
+      return MGS_ERR_INVALID_ARG;
+    }
+    p.zero_ptr = reinterpret_cast<float4*>(a->bwd_accum);
+    p.zero_f4 = a->bwd_accum_bytes / 16;
+  }
+  p.tile_hist = im.tile_hist; p.blk_base = g.blk_base;
+  MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
+  { StageTimer t(ST_PREPROCESS, stream);
+    MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
+  volatile uint64_t* hs = host_status;
+  *hs = kStatusPending;
+  { StageTimer t(ST_SORT, stream);
+    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, at.tiles_x, at.tiles_yv * V, options().seg, host_status, stream),
+            "segment-sort binning (views)"); }
+  const RenderArgs r = views_render_args(a, at, g);
+  { StageTimer t(ST_RENDER_FWD, stream);
+    MGS_HIP(launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (views)"); }
+  uint32_t R = 0, fl = 0;
+  rc = wait_status(host_status, stream, &R, &fl);
+  if (rc) return rc;
+  rc = check_prefiltered(fl);
+  if (rc) return rc;
+  *num_rendered = (int32_t)R;
+  return (int)R > cap ? MGS_NEED_CAPACITY : MGS_OK;
+}
+
+int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t R, const int32_t* radii,
+                                 const float* dL_dout_color, const float* dL_dout_feature, float* dL_dmeans2D,
+                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dfeature,
+                                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
+                                 void* scratch, size_t scratch_bytes, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MgsRasterArgs a1;
+  int rc = check_views(a, V, views, &a1);
+  if (rc) return rc;
+  if (a->P == 0) return MGS_OK;
+  const int F = a->include_feature ? a->F : 0;
+  if (!radii || !dL_dout_color || !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D ||
+      !dL_dscales || !dL_drotations || (a->M > 0 && !dL_dsh) || (F > 0 && (!dL_dfeature || !dL_dout_feature))) {
+    set_error("backward (views): a required pointer is NULL");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const Atlas at = atlas_of(a->W, a->H, V);
+  if (!scratch || scratch_bytes < mgs_views_backward_scratch_bytes(a->P, a->M, F, V) || !a->geom ||
+      a->geom_bytes < mgs_views_geom_bytes(a->P, a->M, a->W, a->H, V) || !a->img ||
+      a->img_bytes < mgs_views_img_bytes(a->W, a->H, V) || !a->binning) {
+    set_error("backward (views): workspace too small");
+    return MGS_ERR_WORKSPACE;
+  }
+  const int cap = binning_capacity(a->binning_bytes, at.T, F, false);
+  if (cap < 0 || R > cap) { set_error("backward (views): binning workspace holds %d instances, need %d", cap, R); return MGS_ERR_WORKSPACE; }
+  const size_t PV = (size_t)a->P * V, P = (size_t)a->P;
+  GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, nullptr);
+  ImgView im = carve_img(a->img, a->W, at.H, nullptr);
+  ChunkView cv;
+  BinView b = carve_binning(a->binning, cap, at.T, F, 64, false, &cv, nullptr);
+  BwdScratch sc = carve_bwd(scratch, (int)PV, a->M, F, nullptr);
+  const size_t ncol = a->colors_precomp ? P : PV;  // dL_dcolors rows: per Gaussian (precomputed colours) or per (view, Gaussian)
+  if (!a->accum_prezeroed) {
+    StageTimer t(ST_BWD_MEMSET, stream);
+    MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * PV * sizeof(float), stream), "memset acc8");
+    MGS_HIP(hipMemsetAsync(dL_dcolors, 0, 3 * ncol * sizeof(float), stream), "memset dL_dcolors");
+    if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
+  }
+  if (R > 0) {
+    const RenderArgs r = views_render_args(a, at, g);
+    StageTimer t(ST_RENDER_BWD, stream);
+    MGS_HIP(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dL_dcolors, dL_dfeature, stream),
+            "render backward (views)");
+  }
+  BwdPreArgs p;
+  p.V = V; p.cov3D_per_view = a->cov3D_precomp ? 0 : 1; p.use_cam = 1;
+  p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
+  p.tanfovx = p.tanfovy = p.focal_x = p.focal_y = 0.f;
+  p.scale_modifier = a->scale_modifier;
+  p.means3D = a->means3D; p.shs = a->shs; p.scales = a->scales; p.rotations = a->rotations;
+  p.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
+  p.viewmatrix = p.projmatrix = p.campos = nullptr;
+  fill_cams(p.cam, a, V, views);
+  p.radii = radii; p.clamped = g.clamped; p.acc8 = sc.acc8; p.dL_dcolor = dL_dcolors;
+  p.dL_dmeans2D = dL_dmeans2D; p.dL_dconic = dL_dconic; p.dL_dopacity = dL_dopacity; p.dL_dmeans3D = dL_dmeans3D;
+  p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh; p.dL_dscales = dL_dscales; p.dL_drot = dL_drotations;
+  { StageTimer t(ST_PREPROCESS_BWD, stream);
+    MGS_HIP(launch_preprocess_bwd(p, stream), "preprocess backward (views)"); }
   return MGS_OK;
 }
 

@@ -206,8 +206,9 @@ struct ViewCam {  // per-view camera of a multi-view batch
 
 struct FwdPreArgs {
   int P, D, M, W, H, tiles_x, tiles_y;
-  int V, Pg, Hp;             // V > 1: P = V * Pg virtual Gaussians, H = view height, tiles_y = tile rows of ONE view
-  ViewCam cam[MAX_VIEWS];    // V > 1 only
+  int V, Pg, Hp;             // P = V * Pg virtual Gaussians, H = view height, tiles_y = tile rows of ONE view
+  int use_cam;               // 1: cameras come from cam[] (the multi-view entry points), 0: from the fields below
+  ViewCam cam[MAX_VIEWS];
   uint32_t* tile_hist;  // [T] instance histogram (zeroed by the caller), or nullptr (legacy binning)
   uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
@@ -265,6 +266,8 @@ hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const Img
 
 struct BwdPreArgs {
   int P, D, M, W, H;
+  int cov3D_per_view;        // cov3D is the forward's [V][P][6] workspace copy (else the caller's [P][6])
+  int use_cam;               // 1: cameras come from cam[] (the multi-view entry points)
   int V;                     // views; P = Gaussians (not virtual); radii, clamped, acc8, dL_dcolor, dL_dmeans2D, dL_dconic
   ViewCam cam[MAX_VIEWS];    // are [V][P][.] when V > 1 and cam[v] replaces the single-view camera fields below
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;

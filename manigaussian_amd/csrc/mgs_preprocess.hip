@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)gridDim.x * blockDim.x)
       a.zero_ptr[i] = z;
   }
-  const bool batch = a.V > 1;
+  const bool batch = a.use_cam != 0;
   const float tanfovx = batch ? a.cam[v].tanfovx : a.tanfovx, tanfovy = batch ? a.cam[v].tanfovy : a.tanfovy;
   const float focal_x = batch ? a.cam[v].focal_x : a.focal_x, focal_y = batch ? a.cam[v].focal_y : a.focal_y;
   if constexpr (HIST) {
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
           g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
         }
         g.depths[idx] = view_z;
-        g.rec[2 * (size_t)idx] = make_float4(px, py + (float)(v * a.Hp), conx, cony);  // atlas row of the view
+        g.rec[2 * (size_t)idx] = make_float4(px, py, conx, cony);  // view-local pixel coordinates
         g.rec[2 * (size_t)idx + 1] = make_float4(conz, opacity, hx, hy);
         radius_out = (int32_t)my_radius;
         touched = (uint32_t)((y1 - y0) * (x1 - x0));
@@ -291,39 +291,47 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.P) return;
   const size_t i = (size_t)idx;
-  const bool vis = a.radii[idx] > 0;
-  float acc[8];
-  {
-    const float4 u = reinterpret_cast<const float4*>(a.acc8)[2 * i];
-    const float4 v = reinterpret_cast<const float4*>(a.acc8)[2 * i + 1];
-    acc[0] = u.x; acc[1] = u.y; acc[2] = u.z; acc[3] = u.w; acc[4] = v.x; acc[5] = v.y;
-  }
-  // render-backward sums: a non-visible Gaussian is in no tile list, so they are already zero.
-  a.dL_dmeans2D[3 * i + 0] = acc[0];
-  a.dL_dmeans2D[3 * i + 1] = acc[1];
-  a.dL_dmeans2D[3 * i + 2] = 0.f;
-  a.dL_dopacity[i] = acc[5];
-  if (a.dL_dconic) {
-    a.dL_dconic[4 * i + 0] = acc[2]; a.dL_dconic[4 * i + 1] = acc[3];
-    a.dL_dconic[4 * i + 2] = 0.f;    a.dL_dconic[4 * i + 3] = acc[4];
-  }
   float g_mean[3] = {0, 0, 0}, g_cov[6] = {0, 0, 0, 0, 0, 0}, g_scale[3] = {0, 0, 0}, g_rot[4] = {0, 0, 0, 0};
+  float g_op = 0.f;
   const int n_sh = a.M;
-  if (!vis) {
-    if (a.dL_dsh)
-      for (int k = 0; k < 3 * n_sh; k++) a.dL_dsh[i * 3 * n_sh + k] = 0.f;
-  } else {
-    const float* __restrict__ vm = a.viewmatrix;
-    const float* __restrict__ proj = a.projmatrix;
-    const V3 m = ld3(a.means3D, idx);
+  bool sh_written = false;  // the first visible view stores the SH gradient, later views add to it
+  const V3 m = ld3(a.means3D, idx);
+  // One pass per view (a single-view call has V == 1): the render-backward sums, the clamp flags, the per-view colour
+  // gradient and the 2D outputs are [V][P][.]; everything per Gaussian is summed over the views in registers.
+  for (int vw = 0; vw < a.V; vw++) {
+    const size_t vi = (size_t)vw * a.P + i;  // instance owner (virtual id)
+    const bool vis = a.radii[vi] > 0;
+    float acc[8];
+    {
+      const float4 u = reinterpret_cast<const float4*>(a.acc8)[2 * vi];
+      const float4 v = reinterpret_cast<const float4*>(a.acc8)[2 * vi + 1];
+      acc[0] = u.x; acc[1] = u.y; acc[2] = u.z; acc[3] = u.w; acc[4] = v.x; acc[5] = v.y;
+    }
+    // render-backward sums: a non-visible Gaussian is in no tile list, so they are already zero.
+    a.dL_dmeans2D[3 * vi + 0] = acc[0];
+    a.dL_dmeans2D[3 * vi + 1] = acc[1];
+    a.dL_dmeans2D[3 * vi + 2] = 0.f;
+    g_op += acc[5];
+    if (a.dL_dconic) {
+      a.dL_dconic[4 * vi + 0] = acc[2]; a.dL_dconic[4 * vi + 1] = acc[3];
+      a.dL_dconic[4 * vi + 2] = 0.f;    a.dL_dconic[4 * vi + 3] = acc[4];
+    }
+    if (!vis) continue;
+    const bool batch = a.use_cam != 0;
+    const float* __restrict__ vm = batch ? a.cam[vw].viewmatrix : a.viewmatrix;
+    const float* __restrict__ proj = batch ? a.cam[vw].projmatrix : a.projmatrix;
+    const float* __restrict__ campos = batch ? a.cam[vw].campos : a.campos;
+    const float tanfovx = batch ? a.cam[vw].tanfovx : a.tanfovx, tanfovy = batch ? a.cam[vw].tanfovy : a.tanfovy;
+    const float focal_x = batch ? a.cam[vw].focal_x : a.focal_x, focal_y = batch ? a.cam[vw].focal_y : a.focal_y;
+    float gc[6] = {0, 0, 0, 0, 0, 0};  // this view's dL_dcov3D
     float c6[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * i + k];
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (a.cov3D_per_view ? vi : i) + k];
     // ---- K9: backward.cu:144-274 ----
-    const ViewCov vc = view_cov(m, vm, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy);
+    const ViewCov vc = view_cov(m, vm, focal_x, focal_y, tanfovx, tanfovy);
     float c00, c01, c11, Va[3], Vb[3];
     cov2d_from(vc, c6, c00, c01, c11, Va, Vb);
-    const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
     const float x_grad_mul = (vc.txtz < -limx || vc.txtz > limx) ? 0.f : 1.f;
     const float y_grad_mul = (vc.tytz < -limy || vc.tytz > limy) ? 0.f : 1.f;
     const float ca = c00 + 0.3f, cb = c01, cc = c11 + 0.3f;
@@ -336,12 +344,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
       dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
       dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
       const float* A = vc.a; const float* B = vc.b;
-      g_cov[0] = A[0] * A[0] * dL_da + A[0] * B[0] * dL_db + B[0] * B[0] * dL_dc;
-      g_cov[3] = A[1] * A[1] * dL_da + A[1] * B[1] * dL_db + B[1] * B[1] * dL_dc;
-      g_cov[5] = A[2] * A[2] * dL_da + A[2] * B[2] * dL_db + B[2] * B[2] * dL_dc;
-      g_cov[1] = 2 * A[0] * A[1] * dL_da + (A[0] * B[1] + A[1] * B[0]) * dL_db + 2 * B[0] * B[1] * dL_dc;
-      g_cov[2] = 2 * A[0] * A[2] * dL_da + (A[0] * B[2] + A[2] * B[0]) * dL_db + 2 * B[0] * B[2] * dL_dc;
-      g_cov[4] = 2 * A[2] * A[1] * dL_da + (A[1] * B[2] + A[2] * B[1]) * dL_db + 2 * B[1] * B[2] * dL_dc;
+      gc[0] = A[0] * A[0] * dL_da + A[0] * B[0] * dL_db + B[0] * B[0] * dL_dc;
+      gc[3] = A[1] * A[1] * dL_da + A[1] * B[1] * dL_db + B[1] * B[1] * dL_dc;
+      gc[5] = A[2] * A[2] * dL_da + A[2] * B[2] * dL_db + B[2] * B[2] * dL_dc;
+      gc[1] = 2 * A[0] * A[1] * dL_da + (A[0] * B[1] + A[1] * B[0]) * dL_db + 2 * B[0] * B[1] * dL_dc;
+      gc[2] = 2 * A[0] * A[2] * dL_da + (A[0] * B[2] + A[2] * B[0]) * dL_db + 2 * B[0] * B[2] * dL_dc;
+      gc[4] = 2 * A[2] * A[1] * dL_da + (A[1] * B[2] + A[2] * B[1]) * dL_db + 2 * B[1] * B[2] * dL_dc;
     }
     float dT0[3], dT1[3];
 #pragma unroll
@@ -354,13 +362,15 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
     const float dJ11 = vm[1] * dT1[0] + vm[5] * dT1[1] + vm[9] * dT1[2];
     const float dJ12 = vm[2] * dT1[0] + vm[6] * dT1[1] + vm[10] * dT1[2];
     const float tz = 1.f / vc.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-    const float hx = a.focal_x, hy = a.focal_y;
+    const float hx = focal_x, hy = focal_y;
     const float dtx = x_grad_mul * -hx * tz2 * dJ02;
     const float dty = y_grad_mul * -hy * tz2 * dJ12;
     const float dtz = -hx * tz2 * dJ00 - hy * tz2 * dJ11 + (2 * hx * vc.tx) * tz3 * dJ02 + (2 * hy * vc.ty) * tz3 * dJ12;
-    g_mean[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;   // transformVec4x3Transpose
-    g_mean[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
-    g_mean[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+    g_mean[0] += vm[0] * dtx + vm[1] * dty + vm[2] * dtz;   // transformVec4x3Transpose
+    g_mean[1] += vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+    g_mean[2] += vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) g_cov[kk] += gc[kk];
     // ---- K10: projection path, backward.cu:369-387 ----
     const float hw = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
     const float m_w = 1.0f / (hw + 0.0000001f);
@@ -372,19 +382,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
     g_mean[2] += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
     // ---- SH backward, backward.cu:20-139 ----
     if (a.shs) {
-      const V3 cam = {a.campos[0], a.campos[1], a.campos[2]};
+      const V3 cam = {campos[0], campos[1], campos[2]};
       const V3 dir_orig = m - cam;
       const float len = sqrtf(dot(dir_orig, dir_orig));
       const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
       const float* __restrict__ sh = a.shs + i * n_sh * 3;
       auto SH = [&](int k) { return v3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
-      const uint8_t cl = a.clamped[idx];
-      V3 dRGB = ld3(a.dL_dcolor, idx);
+      const uint8_t cl = a.clamped[vi];
+      V3 dRGB = ld3(a.dL_dcolor, vi);
       dRGB.x *= (cl & 1) ? 0.f : 1.f;
       dRGB.y *= (cl & 2) ? 0.f : 1.f;
       dRGB.z *= (cl & 4) ? 0.f : 1.f;
       float* __restrict__ o = a.dL_dsh + i * n_sh * 3;
-      auto ST = [&](int k, float w) { o[3 * k] = w * dRGB.x; o[3 * k + 1] = w * dRGB.y; o[3 * k + 2] = w * dRGB.z; };
+      auto ST = [&](int k, float w) {
+        if (sh_written) { o[3 * k] += w * dRGB.x; o[3 * k + 1] += w * dRGB.y; o[3 * k + 2] += w * dRGB.z; }
+        else { o[3 * k] = w * dRGB.x; o[3 * k + 1] = w * dRGB.y; o[3 * k + 2] = w * dRGB.z; }
+      };
       V3 dx = {0, 0, 0}, dy = {0, 0, 0}, dz = {0, 0, 0};
       const float x = dir.x, y = dir.y, z = dir.z;
       ST(0, SH_C0);
@@ -420,6 +433,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
         }
       }
       for (int k = written; k < n_sh; k++) ST(k, 0.f);  // coefficients above the active degree keep zero
+      sh_written = true;
       const V3 dL_ddir = {dot(dx, dRGB), dot(dy, dRGB), dot(dz, dRGB)};
       // dnormvdv, auxiliary.h:107-117
       const V3 v = dir_orig;
@@ -429,7 +443,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
       g_mean[1] += (-v.x * v.y * dL_ddir.x + (sum2 - v.y * v.y) * dL_ddir.y - v.z * v.y * dL_ddir.z) * invsum32;
       g_mean[2] += (-v.x * v.z * dL_ddir.x - v.y * v.z * dL_ddir.y + (sum2 - v.z * v.z) * dL_ddir.z) * invsum32;
     }
-    // ---- cov3D backward, backward.cu:278-341 ----
+  }  // views
+  if (a.dL_dsh && !sh_written)
+    for (int k = 0; k < 3 * n_sh; k++) a.dL_dsh[i * 3 * n_sh + k] = 0.f;
+  a.dL_dopacity[i] = g_op;
+  {
+    // ---- cov3D backward, backward.cu:278-341 (linear in dL_dcov3D: applied once to the sum over the views) ----
     if (a.scales) {
       float R[3][3];
       const float* q = a.rotations + 4 * i;

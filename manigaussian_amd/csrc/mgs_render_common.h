@@ -98,7 +98,8 @@ struct PixBlk {
   int px, py;      // pixel of this lane in ATLAS coordinates (== image coordinates for a single view)
   int v;           // view of the block
   bool inside;
-  float pxf, pyf, bxmin, bxmax, bymin, bymax;
+  float pxf, pyf, bxmin, bxmax, bymin, bymax;  // VIEW-LOCAL pixel / block coordinates (what the records are in): a
+                                               // batched view computes bit for bit what a single-view call computes
   size_t pixl;     // y_local * W + x inside the view's image plane
   size_t pixa;     // atlas pixel index py * W + px (per-pixel workspace state)
 };
@@ -112,9 +113,10 @@ __device__ __forceinline__ PixBlk pix_blk(const RenderArgs& r, int tile, int sub
   p.v = 0;
   if (r.V > 1) { p.v = p.py / r.Hp; yl = p.py - p.v * r.Hp; }
   p.inside = p.px < r.W && yl < r.Hv;
-  p.pxf = (float)p.px; p.pyf = (float)p.py;
+  const int by0l = by0 - p.v * r.Hp;
+  p.pxf = (float)p.px; p.pyf = (float)yl;
   p.bxmin = (float)bx0; p.bxmax = (float)min(bx0 + SUB - 1, r.W - 1);
-  p.bymin = (float)by0; p.bymax = (float)min(by0 + SUB - 1, r.H - 1);
+  p.bymin = (float)by0l; p.bymax = (float)min(by0l + SUB - 1, r.Hv - 1);
   p.pixl = (size_t)yl * r.W + p.px;
   p.pixa = (size_t)p.py * r.W + p.px;
   return p;

@@ -385,6 +385,51 @@ def test_sharded_views_on_gpu_equal_sum_of_views():
         assert (total[k] - acc[k]).abs().max().item() <= 1e-4 * acc[k].abs().max().item() + 1e-9, k
 
 
+# ---- multi-view batches ---------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [dict(P=6000, F=32, V=4, W=128, H=128), dict(P=3000, F=3, V=3, W=72, H=40),
+                                  dict(P=2000, F=5, V=2, W=64, H=64, precomp=True),
+                                  dict(P=20000, F=32, V=8, W=128, H=128)],
+                         ids=["f32_4views", "odd_size_3views", "precomp_colors_padded_f5", "f32_8views"])
+def test_view_batch_equals_per_view_calls(case):
+    """GaussianRasterizerBatch == V GaussianRasterizer calls: images and radii bit for bit (same kernels, same
+    per-pixel arithmetic and order), per-view means2D gradients equal, parameter gradients = sum over the views."""
+    from manigaussian_amd import GaussianRasterizerBatch
+    dev = torch.device("cuda:0")
+    P, F, V, W, H = case["P"], case["F"], case["V"], case["W"], case["H"]
+    precomp = case.get("precomp", False)
+    sc = syn.make_scene(P, F=F, M=4, seed=2, colors_precomp=precomp)
+    cams = syn.circle_cameras(V, W, H, negative_focal=True)
+    sets = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, bg=(0.1, 0.2, 0.3), device=dev))
+            for c in cams]
+    g = torch.Generator().manual_seed(4)
+    dC, dF = torch.randn(V, 3, H, W, generator=g).to(dev), torch.randn(V, F, H, W, generator=g).to(dev)
+
+    def leaves():
+        return {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+
+    def call(rast, d, m2d):
+        kw = dict(colors_precomp=d["colors_precomp"]) if precomp else dict(shs=d["shs"])
+        return rast(d["means3D"], m2d, d["opacities"], language_feature_precomp=d["language_feature"],
+                    scales=d["scales"], rotations=d["rotations"], **kw)
+
+    db = leaves()
+    m2b = torch.zeros(V, P, 3, device=dev, requires_grad=True)
+    cb, fb, rb = call(GaussianRasterizerBatch(sets), db, m2b)
+    torch.autograd.backward([cb, fb], [dC, dF])
+    ds = leaves()
+    acc = None
+    for v in range(V):
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        c, f, r = call(GaussianRasterizer(sets[v]), ds, m2)
+        assert torch.equal(c, cb[v]) and torch.equal(f, fb[v]) and torch.equal(r, rb[v]), f"view {v}"
+        torch.autograd.backward([c, f], [dC[v], dF[v]])
+        assert (m2.grad - m2b.grad[v]).abs().max().item() <= 1e-5 * m2.grad.abs().max().item() + 1e-9
+    for k in ds:
+        ref, got = ds[k].grad, db[k].grad
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k
+
+
 # ---- deformation-field kernels ---------------------------------------------------------------------
 
 def test_deform_apply_and_assembly_match_torch():
