@@ -23,9 +23,11 @@ def _stream(dev):
 
 
 def _c(t):
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"expected float32, got {t.dtype}")
-    return t.contiguous()
+    """contiguous float32 (the kernels are fp32; a bf16/fp16 tensor from an autocast MLP is widened, its gradient is
+    narrowed back by autograd)."""
+    if not t.is_floating_point():
+        raise RuntimeError(f"expected a floating-point tensor, got {t.dtype}")
+    return t.float().contiguous()
 
 
 class _AssembleDeformInput(torch.autograd.Function):
