@@ -191,6 +191,17 @@ int mgs_deform_apply_forward(int N, const float* xyz, const float* rot, const fl
 int mgs_deform_apply_backward(int N, const float* rot, const float* delta, const float* g_xyz_out,
                               const float* g_rot_out, float* g_delta, mgs_stream_t stream);
 
+/* ---- Gaussian-regressor epilogue (MG/models_embed.py:233-253, MG/gaussian_renderer/__init__.py:66-68) ----
+ * raw [N,26] = xyz 3 | opacity 1 | scale 3 | rot 4 | f_dc 3 | feature 3 | f_rest 9 (the split of models_embed.py:121,139-141)
+ *   xyz = xyz_in + raw.xyz;  opacity = sigmoid;  scale = min(exp, 0.05);  rot = normalize (eps 1e-12);
+ *   sh [N,4,3] = (f_dc, f_rest);  feature = raw.feature;  feature_n = feature / (|feature| + 1e-12)
+ * backward: any g_* may be NULL (treated as zero); g_raw [N,26] is fully written. */
+int mgs_regress_epilogue_forward(int N, const float* raw, const float* xyz_in, float* xyz, float* opacity, float* scale,
+                                 float* rot, float* sh, float* feature, float* feature_n, mgs_stream_t stream);
+int mgs_regress_epilogue_backward(int N, const float* raw, const float* g_xyz, const float* g_opacity, const float* g_scale,
+                                  const float* g_rot, const float* g_sh, const float* g_feature, const float* g_feature_n,
+                                  float* g_raw, mgs_stream_t stream);
+
 /* Per-stage device timing (hipEvents on the caller's stream), enabled with
  * mgs_set_option("profile", 1) (render backward only) or 2 (every stage).  mgs_profile_read waits for the
  * recorded events, writes the summed milliseconds and launch counts per stage ([mgs_profile_num_stages()]),

@@ -464,3 +464,39 @@ def test_deform_apply_and_assembly_match_torch():
     assert torch.allclose(nxt["rot"].norm(dim=-1), torch.ones(N, device=dev), atol=1e-5)
     (nxt["xyz"].sum() + nxt["rot"].sum()).backward()
     assert lat.grad is not None and torch.isfinite(lat.grad).all()
+
+
+def test_regressor_epilogue_matches_torch():
+    """manigaussian_amd.regressor.gaussian_epilogue vs the reference's torch ops (models_embed.py:233-253,
+    gaussian_renderer/__init__.py:66-68), forward and backward, including clamped scales and a zero feature row."""
+    from manigaussian_amd.regressor import gaussian_epilogue
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    N = 16384
+    raw0 = torch.randn(1, N, 26, generator=g)
+    raw0[..., 4:7] = raw0[..., 4:7] * 1.5 - 3.5     # exp() on both sides of the 0.05 clamp
+    raw0[0, 5, 14:17] = 0.0                          # zero feature vector
+    xyz0 = torch.randn(1, N, 3, generator=g)
+    raw = raw0.to(dev).requires_grad_(True)
+    xyz_in = xyz0.to(dev).requires_grad_(True)
+    out = gaussian_epilogue(raw, xyz_in)
+    raw_r = raw0.to(dev).requires_grad_(True)
+    xyz_r = xyz0.to(dev).requires_grad_(True)
+    dxyz, op, sc, rt, fdc, feat, frest = raw_r.split([3, 1, 3, 4, 3, 3, 9], dim=-1)
+    ref = dict(xyz=xyz_r + dxyz, opacity=torch.sigmoid(op), scale=torch.clamp_max(torch.exp(sc), 0.05),
+               rot=torch.nn.functional.normalize(rt, dim=-1),
+               sh=torch.cat([fdc.unsqueeze(2), frest.reshape(1, N, -1, 3)], dim=2), feature=feat,
+               feature_normalized=feat / (feat.norm(dim=-1, keepdim=True) + 1e-12))
+    ws = {}
+    for k in ref:
+        assert out[k].shape == ref[k].shape, k
+        assert torch.allclose(out[k], ref[k], atol=1e-6, rtol=1e-5), k
+        ws[k] = torch.randn(ref[k].shape, generator=g).to(dev)
+    (sum((out[k] * ws[k]).sum() for k in ref)).backward()
+    (sum((ref[k] * ws[k]).sum() for k in ref)).backward()
+    assert torch.allclose(raw.grad, raw_r.grad, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(xyz_in.grad, xyz_r.grad)
+    # only some outputs used: the unused ones arrive as None
+    raw.grad = None
+    gaussian_epilogue(raw, xyz_in)["scale"].sum().backward()
+    assert raw.grad[..., :4].abs().max() == 0 and raw.grad[..., 7:].abs().max() == 0
