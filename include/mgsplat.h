@@ -202,6 +202,15 @@ int mgs_regress_epilogue_backward(int N, const float* raw, const float* g_xyz, c
                                   const float* g_rot, const float* g_sh, const float* g_feature, const float* g_feature_n,
                                   float* g_raw, mgs_stream_t stream);
 
+/* ---- per-point latent: voxel-feature trilinear gather + positional encoding (MG/models_embed.py:147-215, MG/utils.py:133-169) ----
+ * out [N, C + 3 + 6K] = [ grid_sample(voxel [C,D,H,W], canon; align_corners, zero padding) | canon | sin/cos(pi 2^k canon) ],
+ * canon = (xyz - bounds[0:3]) / (bounds[3:6] - bounds[0:3]); bounds is a HOST array of 6 floats.
+ * backward: g_voxel [C,D,H,W] += d out[:, 0:C] / d voxel (atomic; zero it first); g_out rows are row_stride floats apart. */
+int mgs_voxel_sample_pe_forward(int N, int C, int D, int H, int W, int K, float freq_factor, const float* bounds_host,
+                                const float* voxel, const float* xyz, float* out, mgs_stream_t stream);
+int mgs_voxel_sample_backward(int N, int C, int D, int H, int W, const float* bounds_host, const float* xyz,
+                              const float* g_out, int row_stride, float* g_voxel, mgs_stream_t stream);
+
 /* Per-stage device timing (hipEvents on the caller's stream), enabled with
  * mgs_set_option("profile", 1) (render backward only) or 2 (every stage).  mgs_profile_read waits for the
  * recorded events, writes the summed milliseconds and launch counts per stage ([mgs_profile_num_stages()]),

@@ -7,5 +7,6 @@ apply.  Native code: manigaussian_amd/csrc (HIP) -> libmgsplat.so, C ABI in incl
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians  # noqa: F401
 from .views import GaussianRasterizerBatch  # noqa: F401
 from .regressor import gaussian_epilogue  # noqa: F401
+from .voxel import point_latent_pe  # noqa: F401
 
 __version__ = "0.1.0"

@@ -75,6 +75,10 @@ _EXPORTS = {
     "mgs_deform_apply_backward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 5 + [c_fp]),
     "mgs_regress_epilogue_forward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 9 + [c_fp]),
     "mgs_regress_epilogue_backward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 9 + [c_fp]),
+    "mgs_voxel_sample_pe_forward": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float)] +
+                                    [c_fp] * 3 + [c_fp]),
+    "mgs_voxel_sample_backward": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)] + [c_fp] * 2 +
+                                  [ctypes.c_int, c_fp, c_fp]),
     "mgs_selftest": (ctypes.c_int, [c_fp]),
     "mgs_profile_num_stages": (ctypes.c_int, []),
     "mgs_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int]),

@@ -500,3 +500,39 @@ def test_regressor_epilogue_matches_torch():
     raw.grad = None
     gaussian_epilogue(raw, xyz_in)["scale"].sum().backward()
     assert raw.grad[..., :4].abs().max() == 0 and raw.grad[..., 7:].abs().max() == 0
+
+
+def test_point_latent_pe_matches_grid_sample_and_positional_encoding():
+    """manigaussian_amd.voxel.point_latent_pe vs the reference's torch ops (models_embed.py:147-215, utils.py:133-169):
+    grid_sample(align_corners=True) incl. points outside the volume, the 39-wide positional code, and the gradient
+    w.r.t. the voxel features."""
+    import math
+    from manigaussian_amd.voxel import point_latent_pe
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    C, G, N = 128, 20, 16384
+    bounds = (-0.3, -0.5, 0.6, 0.7, 0.5, 1.6)
+    vox0 = torch.randn(1, C, G, G + 1, G + 2, generator=g)
+    lo, hi = torch.tensor(bounds[:3]), torch.tensor(bounds[3:])
+    xyz0 = lo + (hi - lo) * (torch.rand(1, N, 3, generator=g) * 1.3 - 0.15)   # some points outside the box
+    vox = vox0.to(dev).requires_grad_(True)
+    out = point_latent_pe(vox, xyz0.to(dev), bounds)
+    # reference ops
+    vr = vox0.to(dev).requires_grad_(True)
+    canon = (xyz0.to(dev) - lo.to(dev)) / (hi.to(dev) - lo.to(dev))
+    grid = (canon * 2 - 1.0).unsqueeze(1).unsqueeze(1)
+    pl = torch.nn.functional.grid_sample(vr, grid, align_corners=True, mode="bilinear").squeeze(2).squeeze(2).permute(0, 2, 1)
+    x = canon.reshape(-1, 3)
+    freqs = torch.repeat_interleave(math.pi * 2.0 ** torch.arange(0, 6), 2).view(1, -1, 1).to(dev)
+    phases = torch.zeros(12, device=dev)
+    phases[1::2] = math.pi * 0.5
+    emb = torch.sin(torch.addcmul(phases.view(1, -1, 1), x.unsqueeze(1).repeat(1, 12, 1), freqs)).view(N, -1)
+    ref = torch.cat((pl.reshape(-1, C), torch.cat((x, emb), dim=-1)), dim=-1)
+    assert out.shape == ref.shape == (N, C + 39)
+    assert torch.allclose(out[:, :C], ref[:, :C], atol=1e-5, rtol=1e-5)
+    assert torch.allclose(out[:, C:C + 3], ref[:, C:C + 3], atol=1e-6)
+    assert (out[:, C + 3:] - ref[:, C + 3:]).abs().max().item() <= 2e-5   # sin of arguments up to 32 pi
+    w = torch.randn(ref.shape, generator=g).to(dev)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    assert torch.allclose(vox.grad, vr.grad, atol=1e-4, rtol=1e-4)
