@@ -4,7 +4,8 @@ gradients of Oracle B (oracle/mgs_oracle.c) and of the HIP kernels, and it is th
 "CPU PyTorch reference rasterizer" of BASELINE.json configs[0].
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/ and bench.py's cpu_baseline leg, never by the
-product path.  Parity unpinned against reference outputs (no fixtures exist).
+product path.  Pinned against outputs of the reference's own kernels on the small cases of
+tests/golden/ref (tests/test_oracle.py::test_oracle_a_matches_reference_kernels).
 
 RAST = third_party/gaussian-splatting/submodules/diff-gaussian-rasterization (reference tree).
 

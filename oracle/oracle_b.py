@@ -1,8 +1,9 @@
 """ctypes front-end for oracle/mgs_oracle.c (Oracle B, the CPU restatement of the reference).
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg, never by the product path.  Parity unpinned against reference outputs (the
-reference has no fixtures and cannot be built here); pinned by oracle_a.py + closed forms.
+cpu_baseline leg, never by the product path.  Pinned against outputs of the reference's own
+kernels (tests/golden/ref, made by oracle/_ref = the reference sources built with hipcc; see
+mgs_oracle.c's header), and by oracle_a.py + closed forms.
 
 Mirrors the call shape of RAST/diff_gaussian_rasterization/__init__.py:_RasterizeGaussians:
 forward(...) -> (color, feature, radii, state); backward(state, dL_dcolor, dL_dfeat) -> grads

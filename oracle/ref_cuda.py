@@ -1,0 +1,97 @@
+"""oracle/ref_cuda.py -- TEST INFRASTRUCTURE ONLY (never imported by manigaussian_amd/).
+
+ctypes front-end of oracle/_ref/libmgs_ref.so: the REFERENCE's own rasterizer
+(RAST/cuda_rasterizer/{forward,backward,rasterizer_impl}.cu, RAST = third_party/gaussian-splatting/submodules/
+diff-gaussian-rasterization) compiled unmodified with hipcc through oracle/refshim (oracle/Makefile, target _ref).  It
+exists to PIN the other two oracles and the HIP path against what the reference itself computes:
+
+  * tests/golden/make_golden_ref.py runs it on the GPU box and writes tests/golden/ref/*.npz (committed);
+  * tests/test_gpu_parity.py::test_live_reference compares the HIP path with it directly when the .so is present.
+
+What is and is not "the reference" here: every kernel and the host orchestration (CudaRasterizer::Rasterizer::forward /
+backward, rasterizer_impl.cu:198-463) are the reference's sources, byte for byte, built for gfx950.  Three things are
+substitutes: glm (an un-vendored submodule, restated in refshim/glm/glm.hpp: vec3/vec4/mat3, column-major), CUB ->
+hipCUB (same radix sort / scan contracts) and the CUDA runtime names -> HIP.  The feature width is the reference build's
+NUM_CHANNELS_language_feature = 3 (RAST/cuda_rasterizer/config.h:16).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libmgs_ref.so")
+_lib = None
+c_fp = ctypes.POINTER(ctypes.c_float)
+c_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH) and torch.cuda.is_available()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(LIB_PATH)
+        L.ref_num_feature_channels.restype = ctypes.c_int
+        L.ref_forward_backward.restype = ctypes.c_int
+        L.ref_forward_backward.argtypes = (
+            [ctypes.c_int] * 5 + [c_fp] * 7 + [ctypes.c_float] + [c_fp] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] +
+            [c_fp] * 2 + [c_fp, c_fp, c_ip] + [c_fp] * 9)
+        _lib = L
+    return _lib
+
+
+def feature_channels() -> int:
+    return int(lib().ref_num_feature_channels())
+
+
+def _f32(t):
+    if t is None:
+        return None, None
+    a = np.ascontiguousarray(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t), np.float32)
+    if a.size == 0:
+        return None, None
+    return a, a.ctypes.data_as(c_fp)
+
+
+def forward_backward(means3D, opacities, settings, d_color, d_feat=None, shs=None, colors_precomp=None,
+                     language_feature=None, scales=None, rotations=None, cov3D_precomp=None):
+    """One forward + backward through the reference kernels.  Returns (color, feat, radii, grads, num_rendered) with
+    the gradient names of oracle_b.backward."""
+    L = lib()
+    F = feature_channels()
+    P = int(means3D.shape[0])
+    M = int(shs.shape[1]) if (shs is not None and shs.numel() != 0) else 0
+    inc = bool(settings.include_feature)
+    H, W = int(settings.image_height), int(settings.image_width)
+    if language_feature is None or language_feature.numel() == 0:
+        language_feature = torch.zeros(P, F)
+    if int(language_feature.shape[1]) != F:
+        raise ValueError(f"the reference build renders exactly {F} feature channels")
+    keep = []
+
+    def p(t):
+        a, ptr = _f32(t)
+        keep.append(a)
+        return ptr
+    z = lambda *s: np.zeros(s, np.float32)
+    color, feat, radii = z(3, H, W), z(F, H, W), np.zeros((max(P, 1),), np.int32)
+    g = dict(means2D=z(P, 3), opacities=z(P, 1), colors_precomp=z(P, 3), language_feature=z(P, F), means3D=z(P, 3),
+             cov3D=z(P, 6), sh=z(P, max(M, 1), 3), scales=z(P, 3), rotations=z(P, 4))
+    o = lambda a: a.ctypes.data_as(c_fp)
+    R = L.ref_forward_backward(
+        P, int(settings.sh_degree), M, W, H, p(settings.bg), p(means3D), p(shs), p(colors_precomp), p(language_feature),
+        p(opacities), p(scales), float(settings.scale_modifier), p(rotations), p(cov3D_precomp), p(settings.viewmatrix),
+        p(settings.projmatrix), p(settings.campos), float(settings.tanfovx), float(settings.tanfovy), int(inc),
+        p(d_color), p(d_feat if inc else None), o(color), o(feat), radii.ctypes.data_as(c_ip), o(g["means2D"]),
+        o(g["opacities"]), o(g["colors_precomp"]), o(g["language_feature"]), o(g["means3D"]), o(g["cov3D"]), o(g["sh"]),
+        o(g["scales"]), o(g["rotations"]))
+    if R < 0:
+        raise RuntimeError(f"reference rasterizer failed ({R})")
+    if M == 0:
+        g["sh"] = np.zeros((P, 0, 3), np.float32)
+    t = torch.from_numpy
+    return t(color), t(feat), t(radii[:P]), {k: t(v) for k, v in g.items()}, int(R)

@@ -1,8 +1,8 @@
 """Generates tests/golden/*.npz: seeded inputs + Oracle B outputs (images, radii, gradients).
 
-The reference (CUDA + un-vendored glm) cannot run here or anywhere in this environment, so these are NOT
-reference outputs: they freeze the oracle (itself pinned by the autograd Oracle A and closed forms in
-tests/test_oracle.py) so that (a) an accidental change of the oracle is caught on CPU and (b) the GPU parity
+These are NOT reference outputs (those live in tests/golden/ref, see make_golden_ref.py; the reference build
+is fixed at 3 feature channels, these cover F = 32 as well): they freeze the oracle (itself pinned by the
+reference goldens, the autograd Oracle A and closed forms in tests/test_oracle.py) so that (a) an accidental change of the oracle is caught on CPU and (b) the GPU parity
 tests have committed vectors that do not depend on the oracle building on the GPU box.
 
   python tests/golden/make_golden.py

@@ -1,6 +1,7 @@
 """Shared helpers for the parity tests: run the same seeded scene through Oracle B (CPU) and the HIP path."""
 import types
 
+import numpy as np
 import torch
 
 from manigaussian_amd import synthetic as syn
@@ -36,6 +37,28 @@ def run_oracle_b(sc, kw, dC, dF):
         cov3D_precomp=sc.get("cov3D_precomp"))
     grads = oracle_b.backward(state, dC, dF)
     return color, feat, radii, grads, state
+
+
+def stored_inputs(z, sc):
+    """The inputs a golden file was generated from (bit-exact), after checking that today's generator still produces
+    them (derived arrays such as cov3D_precomp go through a matmul whose rounding depends on the host CPU)."""
+    out = {}
+    for k, v in sc.items():
+        a = z[f"in_{k}"]
+        assert np.allclose(v.numpy(), a, rtol=1e-5, atol=1e-9), f"scene generator drifted: {k}"
+        out[k] = torch.from_numpy(a)
+    return out
+
+
+def run_reference(sc, kw, dC, dF):
+    """The reference's own kernels (oracle/_ref via oracle/ref_cuda.py; GPU, F = 3 only).  Returns
+    (color, feat, radii, grads by Oracle-B name, num_rendered)."""
+    from oracle import ref_cuda
+    st = types.SimpleNamespace(**kw)
+    return ref_cuda.forward_backward(
+        sc["means3D"], sc["opacities"], st, dC, dF, shs=sc.get("shs"), colors_precomp=sc.get("colors_precomp"),
+        language_feature=sc.get("language_feature"), scales=sc.get("scales"), rotations=sc.get("rotations"),
+        cov3D_precomp=sc.get("cov3D_precomp"))
 
 
 def run_hip(sc, cam, dC, dF, sh_degree, include_feature, bg, device="cuda:0", debug=False):
