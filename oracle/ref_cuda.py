@@ -21,31 +21,33 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_ref", "libmgs_ref.so")
-_lib = None
+# stock build (3 feature channels, config.h:16) and the same sources rebuilt at 32 channels (oracle/Makefile)
+LIB_PATHS = {3: os.path.join(_HERE, "_ref", "libmgs_ref.so"), 32: os.path.join(_HERE, "_ref", "libmgs_ref_f32.so")}
+LIB_PATH = LIB_PATHS[3]
+_libs = {}
 c_fp = ctypes.POINTER(ctypes.c_float)
 c_ip = ctypes.POINTER(ctypes.c_int)
 
 
-def available() -> bool:
-    return os.path.exists(LIB_PATH) and torch.cuda.is_available()
+def available(F: int = 3) -> bool:
+    return F in LIB_PATHS and os.path.exists(LIB_PATHS[F]) and torch.cuda.is_available()
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = ctypes.CDLL(LIB_PATH)
+_INPUTS = ([ctypes.c_int] * 5 + [c_fp] * 7 + [ctypes.c_float] + [c_fp] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] +
+           [c_fp] * 2)
+
+
+def lib(F: int = 3):
+    if F not in _libs:
+        L = ctypes.CDLL(LIB_PATHS[F])
         L.ref_num_feature_channels.restype = ctypes.c_int
         L.ref_forward_backward.restype = ctypes.c_int
-        L.ref_forward_backward.argtypes = (
-            [ctypes.c_int] * 5 + [c_fp] * 7 + [ctypes.c_float] + [c_fp] * 5 + [ctypes.c_float] * 2 + [ctypes.c_int] +
-            [c_fp] * 2 + [c_fp, c_fp, c_ip] + [c_fp] * 9)
-        _lib = L
-    return _lib
-
-
-def feature_channels() -> int:
-    return int(lib().ref_num_feature_channels())
+        L.ref_forward_backward.argtypes = _INPUTS + [c_fp, c_fp, c_ip] + [c_fp] * 9
+        L.ref_bench.restype = ctypes.c_int
+        L.ref_bench.argtypes = _INPUTS + [ctypes.c_int, ctypes.c_int] + [c_fp] * 3
+        assert int(L.ref_num_feature_channels()) == F
+        _libs[F] = L
+    return _libs[F]
 
 
 def _f32(t):
@@ -57,20 +59,26 @@ def _f32(t):
     return a, a.ctypes.data_as(c_fp)
 
 
+def _width(language_feature) -> int:
+    """Which build serves this call: the feature width is a compile-time constant of the reference."""
+    F = int(language_feature.shape[1]) if (language_feature is not None and language_feature.numel() != 0) else 3
+    if F not in LIB_PATHS:
+        raise ValueError(f"no reference build for {F} feature channels (have {sorted(LIB_PATHS)})")
+    return F
+
+
 def forward_backward(means3D, opacities, settings, d_color, d_feat=None, shs=None, colors_precomp=None,
                      language_feature=None, scales=None, rotations=None, cov3D_precomp=None):
     """One forward + backward through the reference kernels.  Returns (color, feat, radii, grads, num_rendered) with
     the gradient names of oracle_b.backward."""
-    L = lib()
-    F = feature_channels()
+    F = _width(language_feature)
+    L = lib(F)
     P = int(means3D.shape[0])
     M = int(shs.shape[1]) if (shs is not None and shs.numel() != 0) else 0
     inc = bool(settings.include_feature)
     H, W = int(settings.image_height), int(settings.image_width)
     if language_feature is None or language_feature.numel() == 0:
         language_feature = torch.zeros(P, F)
-    if int(language_feature.shape[1]) != F:
-        raise ValueError(f"the reference build renders exactly {F} feature channels")
     keep = []
 
     def p(t):
@@ -95,3 +103,30 @@ def forward_backward(means3D, opacities, settings, d_color, d_feat=None, shs=Non
         g["sh"] = np.zeros((P, 0, 3), np.float32)
     t = torch.from_numpy
     return t(color), t(feat), t(radii[:P]), {k: t(v) for k, v in g.items()}, int(R)
+
+
+def bench(means3D, opacities, settings, d_color, d_feat, warmup=10, iters=50, shs=None, colors_precomp=None,
+          language_feature=None, scales=None, rotations=None, cov3D_precomp=None):
+    """Times the reference kernels on this GPU, inputs resident (ref_wrapper.cu:ref_bench).  Returns
+    dict(ms_step, ms_fwd, ms_bwd, num_rendered): per forward+backward pass."""
+    F = _width(language_feature)
+    L = lib(F)
+    P = int(means3D.shape[0])
+    M = int(shs.shape[1]) if (shs is not None and shs.numel() != 0) else 0
+    keep = []
+
+    def p(t):
+        a, ptr = _f32(t)
+        keep.append(a)
+        return ptr
+    out = (ctypes.c_float * 3)()
+    ptr = lambda i: ctypes.cast(ctypes.byref(out, 4 * i), c_fp)
+    R = L.ref_bench(
+        P, int(settings.sh_degree), M, int(settings.image_width), int(settings.image_height), p(settings.bg), p(means3D),
+        p(shs), p(colors_precomp), p(language_feature), p(opacities), p(scales), float(settings.scale_modifier),
+        p(rotations), p(cov3D_precomp), p(settings.viewmatrix), p(settings.projmatrix), p(settings.campos),
+        float(settings.tanfovx), float(settings.tanfovy), int(bool(settings.include_feature)), p(d_color), p(d_feat),
+        int(warmup), int(iters), ptr(0), ptr(1), ptr(2))
+    if R < 0:
+        raise RuntimeError(f"reference bench failed ({R})")
+    return dict(ms_step=out[0] / iters, ms_fwd=out[1] / iters, ms_bwd=out[2] / iters, num_rendered=int(R))

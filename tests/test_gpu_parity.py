@@ -237,17 +237,19 @@ def test_reference_kernel_golden_vectors(path):
 
 
 @pytest.mark.parametrize("case", [
-    dict(P=100000, F=3, W=128, H=128, neg=True, bg=(0.0, 0.0, 0.0), seed=12),           # C3's Gaussian count and image
+    dict(P=100000, F=32, W=128, H=128, neg=True, bg=(0.0, 0.0, 0.0), seed=0, cam_index=0),  # = BASELINE configs[2]
+    dict(P=100000, F=3, W=128, H=128, neg=True, bg=(0.0, 0.0, 0.0), seed=12),               # = BASELINE configs[1]
+    dict(P=20000, F=32, W=200, H=120, neg=False, bg=(0.2, 0.1, 0.0), seed=15, M=9, sh_degree=2),
     dict(P=30000, F=3, W=256, H=192, neg=False, bg=(0.3, 0.3, 0.3), seed=13, M=16, sh_degree=3),
     dict(P=50000, F=3, W=128, H=128, neg=True, colors_precomp=True, include_feature=False, seed=14),
-], ids=["c3_p100k_f3", "sh3_256x192", "precomp_rgb_only_50k"])
+], ids=["c3_p100k_f32", "c2_p100k_f3", "f32_sh2_200x120", "sh3_256x192", "precomp_rgb_only_50k"])
 def test_live_reference(case):
     """The HIP path against the reference's own kernels run LIVE on this GPU (oracle/_ref/libmgs_ref.so, prebuilt in the
-    development container from /root/reference; the GPU box never reads /root/reference).  Skipped where the library
-    was not built."""
+    development container from /root/reference; the GPU box never reads /root/reference; the F = 32 cases use the same
+    sources rebuilt at that feature width).  Skipped where the library was not built."""
     from oracle import ref_cuda
-    if not ref_cuda.available():
-        pytest.skip("oracle/_ref/libmgs_ref.so not built (needs /root/reference at build time)")
+    if not ref_cuda.available(case["F"]):
+        pytest.skip("oracle/_ref/libmgs_ref*.so not built (needs /root/reference at build time)")
     sc, cam, kw, dC, dF = util.scene_case(**case)
     inc = case.get("include_feature", True)
     cr, fr, rr, gr, R = util.run_reference(sc, kw, dC, dF)
