@@ -211,6 +211,21 @@ int mgs_voxel_sample_pe_forward(int N, int C, int D, int H, int W, int K, float 
 int mgs_voxel_sample_backward(int N, int C, int D, int H, int W, const float* bounds_host, const float* xyz,
                               const float* g_out, int row_stride, float* g_voxel, mgs_stream_t stream);
 
+/* ---- camera calibration: replaces NeuralRenderer.get_novel_calib (MG/neural_rendering.py:205-248)
+ * with getWorld2View2 / getProjectionMatrix / focal2fov (MG/graphics_utils.py:17-53) folded in.
+ * c2w [V,16] = the saved cam2world extrinsics, K [V,9] = intrinsics, both row-major float32.  Outputs (any may be NULL):
+ * world_view_transform [V,16], full_proj_transform [V,16] (the transposed matrices the rasterizer takes),
+ * camera_center [V,3], fov [V,2] = (FovX, FovY) (negative for negative focal lengths, kept), tanfov [V,2] = tan(Fov/2).
+ * mgs_novel_calib: device pointers, one launch on `stream`, no host synchronisation; *singular (device int32, optional,
+ * zeroed by the caller) is set to 1 if some cam2world matrix is not invertible.
+ * mgs_novel_calib_host: the same routine on host arrays (what a data-loader cache calls once per camera file). */
+int mgs_novel_calib(int V, const float* c2w, const float* K, int W, int H, float znear, float zfar, float trans_x,
+                    float trans_y, float trans_z, float scale, float* world_view_transform, float* full_proj_transform,
+                    float* camera_center, float* fov, float* tanfov, int32_t* singular, mgs_stream_t stream);
+int mgs_novel_calib_host(int V, const float* c2w, const float* K, int W, int H, float znear, float zfar, float trans_x,
+                         float trans_y, float trans_z, float scale, float* world_view_transform,
+                         float* full_proj_transform, float* camera_center, float* fov, float* tanfov);
+
 /* Per-stage device timing (hipEvents on the caller's stream), enabled with
  * mgs_set_option("profile", 1) (render backward only) or 2 (every stage).  mgs_profile_read waits for the
  * recorded events, writes the summed milliseconds and launch counts per stage ([mgs_profile_num_stages()]),

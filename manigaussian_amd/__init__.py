@@ -8,5 +8,6 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, raste
 from .views import GaussianRasterizerBatch  # noqa: F401
 from .regressor import gaussian_epilogue  # noqa: F401
 from .voxel import point_latent_pe  # noqa: F401
+from . import camera  # noqa: F401
 
 __version__ = "0.1.0"

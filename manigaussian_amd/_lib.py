@@ -79,6 +79,10 @@ _EXPORTS = {
                                     [c_fp] * 3 + [c_fp]),
     "mgs_voxel_sample_backward": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)] + [c_fp] * 2 +
                                   [ctypes.c_int, c_fp, c_fp]),
+    "mgs_novel_calib": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 6 +
+                        [c_fp] * 5 + [c_fp, c_fp]),
+    "mgs_novel_calib_host": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 6 +
+                             [c_fp] * 5),
     "mgs_selftest": (ctypes.c_int, [c_fp]),
     "mgs_profile_num_stages": (ctypes.c_int, []),
     "mgs_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int]),

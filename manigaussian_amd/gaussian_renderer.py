@@ -23,9 +23,14 @@ def render(data, idx, pts_xyz, rotations, scales, opacity, bg_color, pts_rgb=Non
     except Exception:
         pass
     view = data["novel_view"]
+    if "tanfov_host" in view:  # manigaussian_amd.camera.TargetCache: host copies, no device read-back per view
+        tanfovx, tanfovy = view["tanfov_host"][idx]
+        height, width = view["size_host"][idx]
+    else:                      # the reference's dict: four scalar device reads (gaussian_renderer/__init__.py:35-39)
+        tanfovx, tanfovy = math.tan(view["FovX"][idx] * 0.5), math.tan(view["FovY"][idx] * 0.5)
+        height, width = int(view["height"][idx]), int(view["width"][idx])
     settings = GaussianRasterizationSettings(
-        image_height=int(view["height"][idx]), image_width=int(view["width"][idx]),
-        tanfovx=math.tan(view["FovX"][idx] * 0.5), tanfovy=math.tan(view["FovY"][idx] * 0.5),
+        image_height=height, image_width=width, tanfovx=tanfovx, tanfovy=tanfovy,
         bg=bg, scale_modifier=1.0, viewmatrix=view["world_view_transform"][idx],
         projmatrix=view["full_proj_transform"][idx], sh_degree=3 if features_color is None else 1,
         campos=view["camera_center"][idx], prefiltered=False, debug=False,

@@ -69,3 +69,47 @@ def fb2(fn):
 
 
 print(f"regressor epilogue, N={N}: fwd hip {timeit(hip_epi):.0f} us | torch {timeit(ref_epi):.0f} us ; fwd+bwd hip {timeit(fb2(hip_epi)):.0f} us | torch {timeit(fb2(ref_epi)):.0f} us")
+
+# --- camera calibration: the reference's per-step host round trip vs one kernel / a cache hit
+import math  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from manigaussian_amd import camera, synthetic as syn  # noqa: E402
+
+bs, Wc, Hc = 2, 128, 128   # update() calibrates the current and the next frame's camera
+c2w = np.stack([syn.look_at_c2w((1.5, 0.3 * i, 1.8), (0.2, 0.0, 0.9), flip_xy=True) for i in range(bs)])
+Kc = np.stack([np.array([[-175.8, 0, 64.0], [0, -175.8, 64.0], [0, 0, 1.0]])] * bs)
+data = {"intr": torch.from_numpy(Kc).float().to(dev), "extr": torch.from_numpy(c2w).float().to(dev)}
+
+
+def ref_calib():
+    """NeuralRenderer.get_novel_calib's data flow (neural_rendering.py:217-248) with the restated math, followed by the
+    four scalar read-backs render() does per view (gaussian_renderer/__init__.py:35-39)."""
+    cams = [syn.novel_calib(data["extr"][i].cpu().numpy(), data["intr"][i].cpu().numpy().astype(np.float64), Wc, Hc)
+            for i in range(bs)]
+    nv = {"FovX": torch.FloatTensor(np.array([c["FovX"] for c in cams])).to(dev),
+          "FovY": torch.FloatTensor(np.array([c["FovY"] for c in cams])).to(dev),
+          "width": torch.tensor([Wc] * bs).to(dev), "height": torch.tensor([Hc] * bs).to(dev),
+          "world_view_transform": torch.stack([c["world_view_transform"] for c in cams]).to(dev),
+          "full_proj_transform": torch.stack([c["full_proj_transform"] for c in cams]).to(dev),
+          "camera_center": torch.stack([c["camera_center"] for c in cams]).to(dev)}
+    for i in range(bs):
+        math.tan(nv["FovX"][i] * 0.5), math.tan(nv["FovY"][i] * 0.5), int(nv["height"][i]), int(nv["width"][i])
+    return nv
+
+
+def host_time(fn, n=200):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+print(f"camera calibration, {bs} cameras per step (host wall time incl. synchronisations): reference flow "
+      f"{host_time(ref_calib):.0f} us | device kernel (no sync) {host_time(lambda: camera.get_novel_calib(data, Wc, Hc)):.0f} us")
