@@ -143,6 +143,7 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "bwd_mode")) o.bwd_mode = value;
   else if (!strcmp(key, "dbg")) o.dbg = value;
   else if (!strcmp(key, "fwd_mode")) o.fwd_mode = value;
+  else if (!strcmp(key, "dense_variant")) o.dense_variant = value;
   else if (!strcmp(key, "gm_waves")) o.gm_waves = value;
   else if (!strcmp(key, "seg")) {
     if (value != 512 && value != 1024 && value != 2048) { set_error("seg must be 512, 1024 or 2048"); return MGS_ERR_INVALID_ARG; }
@@ -163,6 +164,7 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "bin_mode")) return o.bin_mode;
   if (!strcmp(key, "bwd_mode")) return o.bwd_mode;
   if (!strcmp(key, "fwd_mode")) return o.fwd_mode;
+  if (!strcmp(key, "dense_variant")) return o.dense_variant;
   if (!strcmp(key, "gm_waves")) return o.gm_waves;
   if (!strcmp(key, "seg")) return o.seg;
   set_error("unknown option %s", key);
@@ -174,15 +176,24 @@ static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE
 static bool segsort_binning(int T) { return options().bin_mode == 1 && T <= LDS_TILES; }
 size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
+static int chunk_size();
+// survivor-dense chunks (mgs_render_dense.hip + the DENSE Gaussian-major backward): the default pair of render kernels
+static bool dense_render() {
+  const Options& o = options();
+  return o.render_mode == 2 && chunk_size() == 64 && o.fwd_mode == 2 && o.bwd_mode == 1;
+}
+static int carve_chunk();
 static int chunk_size() {  // 0 when the chunk-parallel render is off
   const Options& o = options();
   if (o.render_mode != 1 && o.render_mode != 2) return 0;
   int ch = o.chunk < 64 ? 64 : o.chunk;
   return (ch + 63) / 64 * 64;
 }
+// chunk size the per-chunk render state is laid out for: SURVIVORS with the dense kernels, `chunk` entries otherwise
+static int carve_chunk() { return dense_render() ? (options().dense_variant == 2 ? 32 : 64) : chunk_size(); }
 size_t mgs_binning_bytes(int R, int W, int H, int F) {
   size_t t;
-  carve_binning(nullptr, R, num_tiles(W, H), F, chunk_size(), !segsort_binning(num_tiles(W, H)), nullptr, &t);
+  carve_binning(nullptr, R, num_tiles(W, H), F, carve_chunk(), !segsort_binning(num_tiles(W, H)), nullptr, &t);
   return t;
 }
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
@@ -194,14 +205,14 @@ static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy);
 static int binning_capacity(size_t bytes, int T, int F, bool legacy) {
   struct Memo { size_t bytes; int T, F, ch, legacy, cap; };
   static thread_local Memo memo = {0, -1, -1, -1, -1, -1};
-  if (memo.bytes == bytes && memo.T == T && memo.F == F && memo.ch == chunk_size() && memo.legacy == (int)legacy)
+  if (memo.bytes == bytes && memo.T == T && memo.F == F && memo.ch == carve_chunk() && memo.legacy == (int)legacy)
     return memo.cap;
   const int cap_ = binning_capacity_uncached(bytes, T, F, legacy);
-  memo = {bytes, T, F, chunk_size(), (int)legacy, cap_};
+  memo = {bytes, T, F, carve_chunk(), (int)legacy, cap_};
   return cap_;
 }
 static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy) {
-  auto need = [&](int R) { size_t t; carve_binning(nullptr, R, T, F, chunk_size(), legacy, nullptr, &t); return t; };
+  auto need = [&](int R) { size_t t; carve_binning(nullptr, R, T, F, carve_chunk(), legacy, nullptr, &t); return t; };
   if (need(0) > bytes) return -1;
   int lo = 0, hi = 1;
   while (hi < (1 << 30) && need(hi) <= bytes) { lo = hi; hi <<= 1; }
@@ -316,7 +327,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
     return MGS_ERR_WORKSPACE;
   }
   ChunkView cv;
-  const int CH = chunk_size();
+  const int CH = carve_chunk();
   BinView b = carve_binning(a->binning, cap, T, F, CH, !segsort, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
@@ -340,7 +351,10 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
   { StageTimer t(ST_RENDER_FWD, stream);
-    if (CH > 0 && options().render_mode == 2)
+    if (dense_render())
+      MGS_STAGE(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, stream), "render forward (dense chunks)",
+                a->debug, stream);
+    else if (CH > 0 && options().render_mode == 2)
       MGS_STAGE(launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (coop)",
                 a->debug, stream);
     else if (CH > 0)
@@ -471,7 +485,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   GeomView g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
-  const int CH = chunk_size();
+  const int CH = carve_chunk();
   BinView b = carve_binning(a->binning, cap, num_tiles(a->W, a->H), F, CH, !segsort, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, a->P, a->M, F, nullptr);
   const size_t P = (size_t)a->P;
@@ -505,8 +519,9 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;
     StageTimer t(ST_RENDER_BWD, stream);
-    if (CH == 64 && options().render_mode == 2 && options().bwd_mode == 1)
-      MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
+    if ((CH == 64 || dense_render()) && options().render_mode == 2 && options().bwd_mode == 1)
+      MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
+                                     dense_render(), stream),
                 "render backward (gaussian-major)", a->debug, stream);
     else if (CH > 0 && options().render_mode == 2)
       MGS_STAGE(launch_render_bwd_coop(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
@@ -561,8 +576,8 @@ static int check_views(const MgsRasterArgs* a, int V, const MgsView* views, MgsR
     if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].campos) { set_error("view %d: NULL matrix", v); return MGS_ERR_INVALID_ARG; }
   const Options& o = options();
   const Atlas at = atlas_of(a->W, a->H, V);
-  if (o.render_mode != 2 || chunk_size() != 64 || o.fwd_mode != 1 || o.bwd_mode != 1 || !segsort_binning(at.T) || a->debug) {
-    set_error("multi-view batches need the default kernels (render_mode 2, chunk 64, fwd_mode 1, bwd_mode 1, bin_mode 1, "
+  if (o.render_mode != 2 || chunk_size() != 64 || (o.fwd_mode != 1 && o.fwd_mode != 2) || o.bwd_mode != 1 || !segsort_binning(at.T) || a->debug) {
+    set_error("multi-view batches need the default kernels (render_mode 2, chunk 64, fwd_mode 1 or 2, bwd_mode 1, bin_mode 1, "
               "debug 0) and V * tiles <= %d (got %d)", LDS_TILES, at.T);
     return MGS_ERR_INVALID_ARG;
   }
@@ -630,7 +645,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   g.flags = im.flags;
   ChunkView cv;
-  BinView b = carve_binning(a->binning, cap, at.T, F, 64, false, &cv, nullptr);
+  BinView b = carve_binning(a->binning, cap, at.T, F, carve_chunk(), false, &cv, nullptr);
   FwdPreArgs p;
   p.V = V; p.Pg = a->P; p.Hp = at.Hp; p.use_cam = 1;
   p.P = a->P * V; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
@@ -662,7 +677,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
             "segment-sort binning (views)"); }
   const RenderArgs r = views_render_args(a, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);
-    MGS_HIP(launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (views)"); }
+    MGS_HIP(dense_render() ? launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, stream)
+                           : launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (views)"); }
   uint32_t R = 0, fl = 0;
   rc = wait_status(host_status, stream, &R, &fl);
   if (rc) return rc;
@@ -701,7 +717,7 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
   GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   ChunkView cv;
-  BinView b = carve_binning(a->binning, cap, at.T, F, 64, false, &cv, nullptr);
+  BinView b = carve_binning(a->binning, cap, at.T, F, carve_chunk(), false, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, (int)PV, a->M, F, nullptr);
   const size_t ncol = a->colors_precomp ? P : PV;  // dL_dcolors rows: per Gaussian (precomputed colours) or per (view, Gaussian)
   if (!a->accum_prezeroed) {
@@ -713,7 +729,8 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
   if (R > 0) {
     const RenderArgs r = views_render_args(a, at, g);
     StageTimer t(ST_RENDER_BWD, stream);
-    MGS_HIP(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dL_dcolors, dL_dfeature, stream),
+    MGS_HIP(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dL_dcolors, dL_dfeature,
+                                 dense_render(), stream),
             "render backward (views)");
   }
   BwdPreArgs p;

@@ -88,6 +88,11 @@ struct ChunkView {
   uint32_t* last_pos;     // [items][64]
   float* q;               // [items][64]
   float* partial;         // [items][3+F][64]
+  // survivor-dense chunks (fwd_mode 2): per 8x8 block the in-order list of entries that reach it, kept for the backward
+  float* T_mid;           // [items][64]  transmittance after the first 32 survivors of a chunk
+  uint2* surv;            // [4][surv_stride]  block (tile, sub): surv[sub * surv_stride + ranges[tile].x + i] = {entry, id}
+  size_t surv_stride;     // = capacity of the instance list
+  uint32_t* nsurv;        // [T*4]  survivors found by the forward (a prefix of the block's full list)
 };
 
 size_t scan_temp_bytes(int P);
@@ -156,6 +161,10 @@ inline BinView carve_binning(void* p, int R, int T, int F, int CH, bool legacy, 
     v.last_pos = c.take<uint32_t>(items * 64);
     v.q = c.take<float>(items * 64);
     v.partial = c.take<float>(items * (size_t)(3 + F) * 64);
+    v.T_mid = c.take<float>(items * 64);
+    v.surv = c.take<uint2>(4 * Ra);
+    v.surv_stride = Ra;
+    v.nsurv = c.take<uint32_t>((size_t)T * 4);
     if (cv) *cv = v;
   }
   if (total) *total = c.total();
@@ -189,7 +198,9 @@ struct Options {
   int bwd_mode = 1;        // render_mode 2, chunk 64: 1 = Gaussian-major backward (scans + fp32 MFMA), 0 = pixel-major + butterfly
   int gm_waves = 16;       // waves per workgroup of the Gaussian-major backward (8 or 16)
   int dbg = 0;             // see RenderArgs::dbg
-  int fwd_mode = 1;        // render_mode 2, chunk 64: 1 = prefetching forward with the image sum in LDS, 0 = original
+  int dense_variant = 1;   // fwd_mode 2: survivors per chunk: 1 = 64 (two full backward groups), 2 = 32
+  int fwd_mode = 2;        // render_mode 2, chunk 64: 2 = survivor-dense chunks + MFMA blend (mgs_render_dense.hip),
+                           // 1 = entry chunks, LDS-staged rows (coop_fwd64_kernel), 0 = original
   int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: legacy rocPRIM scan + radix sort
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
 };
@@ -248,6 +259,8 @@ hipError_t launch_render_bwd(const RenderArgs& r, const BinView& b, const ImgVie
                              const float* dL_dfeat_px, float* acc8, float* dL_dcolors, float* dL_dfeat,
                              hipStream_t s);
 
+hipError_t launch_render_fwd_dense(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
+                                   float* out_color, float* out_feat, hipStream_t s);
 hipError_t launch_render_fwd_chunked(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
                                      float* out_color, float* out_feat, hipStream_t s);
 hipError_t launch_render_bwd_chunked(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
@@ -262,7 +275,7 @@ hipError_t launch_render_bwd_coop(const RenderArgs& r, const BinView& b, const I
 
 hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
                                 const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
-                                float* dL_dfeat, hipStream_t s);
+                                float* dL_dfeat, bool dense, hipStream_t s);
 
 struct BwdPreArgs {
   int P, D, M, W, H;

@@ -41,7 +41,9 @@ __device__ __forceinline__ float gm_exp(float x) { return exp_<FAST>(x); }
 // Per-wave LDS record of one compacted entry: {index into the tile's sorted instance list, 1-based position in the chunk}
 struct GmRec { float4 g0, g1; uint32_t id, pos; };
 
-template <int F, bool FAST, bool EXACT, int NW>
+// DENSE: the forward was coop_fwd_dense_kernel (mgs_render_dense.hip): a chunk is 64 consecutive SURVIVORS of this block's
+// compacted list `surv` (no culling here, groups are full) and T_mid is the transmittance entering the second group.
+template <int F, bool FAST, bool EXACT, int NW, bool DENSE>
 __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ inst,
@@ -52,7 +54,10 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
                                                           const float* __restrict__ final_T,
                                                           const float* __restrict__ dL_dpix,
                                                           const float* __restrict__ dL_dpix_F, float* __restrict__ acc8,
-                                                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat) {
+                                                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat,
+                                                          const float* __restrict__ T_mid,
+                                                          const uint2* __restrict__ surv, size_t surv_stride,
+                                                          const uint32_t* __restrict__ nsurv) {
   using C = GmCfg<F>;
   constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
   __shared__ float dLT[KCH][64];          // [channel][pixel]: A operand of the D contraction
@@ -130,6 +135,8 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
   const int n = lane & 31, h = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
+  uint32_t nsb = 0;                          // DENSE: survivors the forward listed for this block
+  if constexpr (DENSE) nsb = nsurv[(size_t)tile * 4 + sub];
 
   for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
     // ---- pixel-lane: state of this chunk for my pixel ----
@@ -144,23 +151,41 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       B += (live && c2 < lc) ? v : 0.f;
     }
     const float T_in = (live && c > 0) ? T_end[chunk_slot(rng.x, tile, CH, c - 1, sub) * 64 + lane] : 1.0f;
-    // ---- entry-lane: cull + compact the chunk's entries that reach this 8x8 block ----
-    const uint32_t e = rng.x + c * (uint32_t)CH + (uint32_t)lane;
-    const bool valid = e < rng.y && (uint32_t)lane + 1u <= kmax;
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
-    uint32_t id_e = 0;
-    if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; id_e = point_list[e]; }
-    const bool surv = valid && cull_ok<EXACT>(g0, g1, p);
-    const unsigned long long smask = ballot(surv);
-    const int ns = __builtin_popcountll(smask);
-    if (ns == 0) continue;
-    wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
-    pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), 1.0f);
-    if (surv) {
-      const int rk = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
-      rec0[w][rk] = g0; rec1[w][rk] = g1; recid[w][rk] = make_uint2(id_e, (uint32_t)lane + 1u);
+    // ---- entry-lane: the chunk's entries that reach this 8x8 block, compacted in order ----
+    int ns;
+    if constexpr (DENSE) {
+      const uint32_t first = c * (uint32_t)CH;
+      const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
+      ns = (int)min(nin, kmax);
+      if (ns == 0) continue;
+      float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+      uint32_t id_e = 0;
+      if (lane < ns) {
+        const uint2 ei = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
+        g0 = inst[2 * (size_t)ei.x]; g1 = inst[2 * (size_t)ei.x + 1]; id_e = ei.y;
+      }
+      wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
+      pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
+      rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = make_uint2(id_e, (uint32_t)lane + 1u);
+      wave_lds_sync();
+    } else {
+      const uint32_t e = rng.x + c * (uint32_t)CH + (uint32_t)lane;
+      const bool valid = e < rng.y && (uint32_t)lane + 1u <= kmax;
+      float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+      uint32_t id_e = 0;
+      if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; id_e = point_list[e]; }
+      const bool surv_e = valid && cull_ok<EXACT>(g0, g1, p);
+      const unsigned long long smask = ballot(surv_e);
+      ns = __builtin_popcountll(smask);
+      if (ns == 0) continue;
+      wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
+      pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), 1.0f);
+      if (surv_e) {
+        const int rk = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
+        rec0[w][rk] = g0; rec1[w][rk] = g1; recid[w][rk] = make_uint2(id_e, (uint32_t)lane + 1u);
+      }
+      wave_lds_sync();
     }
-    wave_lds_sync();
     const int ngroups = (ns + 31) >> 5;
 
     // ---- Gaussian-lane: groups of <= 32 entries, last group first (suffix sums run back to front) ----
@@ -180,7 +205,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       const uint32_t gidn = gauss_of(r, id);      // the Gaussian: feature row, feature gradient
       const uint32_t cid = r.colors_per_view ? id : gidn;
 
-      if (g == 1) {
+      if (!DENSE && g == 1) {
         // group 1 starts from T_in * prod over group 0 of (1 - alpha): a light pass over group 0's entries
         GmRec r0;  // group 0 is full when a group 1 exists
         r0.g0 = rec0[w][n]; r0.g1 = rec1[w][n]; r0.pos = recid[w][n].y; r0.id = 0;
@@ -336,13 +361,15 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
 // ------------------------------------------- dispatch ------------------------------------------------
 template <int F>
 static hipError_t gm_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, const float* dc,
-                       const float* df, float* acc8, float* dcol, float* dfeat, hipStream_t s) {
+                       const float* df, float* acc8, float* dcol, float* dfeat, bool dense, hipStream_t s) {
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_GM(FAST, EXACT, NW)                                                                                      \
-  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, EXACT, NW>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges,       \
+#define MGS_GM_(FAST, EXACT, NW, DENSE)                                                                               \
+  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, EXACT, NW, DENSE>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges, \
                      b.point_list, b.inst, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, \
-                     acc8, dcol, dfeat)
+                     acc8, dcol, dfeat, cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
+#define MGS_GM(FAST, EXACT, NW)                                                                                       \
+  do { if (dense) MGS_GM_(FAST, true, NW, true); else MGS_GM_(FAST, EXACT, NW, false); } while (0)
   // 8 waves per workgroup: 256 registers per lane (no spills); 16 waves: more latency hiding, 128 registers
   bool launched = false;
   if constexpr (F <= 32) {
@@ -356,15 +383,16 @@ static hipError_t gm_F(const RenderArgs& r, const BinView& b, const ImgView& im,
     if (r.fast_exp) MGS_GM(true, true, 8); else MGS_GM(false, true, 8);
   }
 #undef MGS_GM
+#undef MGS_GM_
   return hipGetLastError();
 }
 
 hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
                                 const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
-                                float* dL_dfeat, hipStream_t s) {
+                                float* dL_dfeat, bool dense, hipStream_t s) {
   const int F = r.include_feature ? r.F : 0;
   switch (F) {
-#define X(N) case N: return gm_F<N>(r, b, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, s);
+#define X(N) case N: return gm_F<N>(r, b, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, dense, s);
     MGS_FOR_EACH_F(X)
 #undef X
     default: return hipErrorInvalidValue;

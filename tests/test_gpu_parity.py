@@ -99,13 +99,16 @@ def test_reference_reduction_variant_agrees():
     _lib.set_option("bwd_reduce", 1)
 
 
-_DEFAULTS = dict(render_mode=2, chunk=64, fwd_mode=1, bwd_mode=1, gm_waves=16, bin_mode=1, seg=2048, exact_cull=1,
-                 fast_exp=1, tight_bins=1)
+_DEFAULTS = dict(render_mode=2, chunk=64, fwd_mode=2, dense_variant=1, bwd_mode=1, gm_waves=16, bin_mode=1, seg=2048,
+                 exact_cull=1, fast_exp=1, tight_bins=1)
 VARIANTS = {
     "legacy_rocprim_binning": dict(bin_mode=0),
     "segments_512": dict(seg=512), "segments_1024": dict(seg=1024),
-    "pixel_major_backward": dict(bwd_mode=0),
-    "gaussian_major_backward_8_waves": dict(gm_waves=8),
+    "dense_chunks_of_32": dict(dense_variant=2),
+    "dense_gaussian_major_backward_8_waves": dict(gm_waves=8),
+    "entry_chunks_lds_rows": dict(fwd_mode=1),
+    "entry_chunks_pixel_major_backward": dict(fwd_mode=1, bwd_mode=0),
+    "entry_chunks_gaussian_major_backward_8_waves": dict(fwd_mode=1, gm_waves=8),
     "original_forward": dict(fwd_mode=0),
     "chunk_128_generic_kernels": dict(chunk=128),
     "per_block_walk": dict(render_mode=0),
