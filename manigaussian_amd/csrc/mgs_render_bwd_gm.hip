@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   __shared__ uint2 recid[NW][64];                // ... {Gaussian id, 1-based position in the chunk}
   constexpr int TROW = NCT * 32 + 9;      // per wave: [32 Gaussians][feature sums | 9 scalar sums], odd stride
   __shared__ float trbuf[NW][32 * TROW];
-  __shared__ uint32_t gid[NW][32];
+  __shared__ uint2 gid[NW][32];           // per wave: {instance id, Gaussian} of the group's lanes (0xffffffff: empty lane)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
 #pragma unroll
         for (int i = 0; i < 9; i++) v[i] += __uint_as_float(lane_xor<32>(__float_as_uint(v[i]), lane));
         float* tr = trbuf[w];
-        if (h == 0) gid[w][n] = has ? id : 0xffffffffu;
+        if (h == 0) gid[w][n] = has ? make_uint2(id, gidn) : make_uint2(0xffffffffu, 0u);
         if constexpr (NCT > 0) {
           if (use_feat) {
 #pragma unroll
@@ -333,23 +333,23 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
 #pragma unroll
             for (int k = 0; k < 16 * NCT; k++) {  // instruction k: Gaussians 2k', 2k'+1 of the tile half, 32 channels each
               const int gg = 2 * (k % 16) + h, ch = 32 * (k / 16) + n;
-              const uint32_t gi2 = gid[w][gg];
-              if (gi2 != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gauss_of(r, gi2) * F + ch, tr[gg * TROW + ch]);
+              const uint2 gi2 = gid[w][gg];
+              if (gi2.x != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gi2.y * F + ch, tr[gg * TROW + ch]);
             }
           }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {  // geometry sums: 8 Gaussians x 8 slots (6 used) per instruction
           const int gg = 8 * k + (lane >> 3), i = lane & 7;
-          const uint32_t gi2 = gid[w][gg];
+          const uint32_t gi2 = gid[w][gg].x;
           if (gi2 != 0xffffffffu && i < 6) unsafeAtomicAdd(acc8 + (size_t)gi2 * 8 + i, tr[gg * TROW + NCT * 32 + i]);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {  // colour sums: 16 Gaussians x 4 slots (3 used) per instruction
           const int gg = 16 * k + (lane >> 2), i = lane & 3;
-          const uint32_t gi2 = gid[w][gg];
-          if (gi2 != 0xffffffffu && i < 3)
-            unsafeAtomicAdd(dL_dcolors + (size_t)(r.colors_per_view ? gi2 : gauss_of(r, gi2)) * 3 + i,
+          const uint2 gi2 = gid[w][gg];
+          if (gi2.x != 0xffffffffu && i < 3)
+            unsafeAtomicAdd(dL_dcolors + (size_t)(r.colors_per_view ? gi2.x : gi2.y) * 3 + i,
                             tr[gg * TROW + NCT * 32 + 6 + i]);
         }
         wave_lds_sync();  // tr / gid are rewritten by the next group

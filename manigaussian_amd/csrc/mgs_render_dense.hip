@@ -144,13 +144,13 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     float rowv[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) rowv[i] = 0.f;
-    uint32_t idl = 0;
+    uint32_t gidl = 0;  // Gaussian (feature row) of my entry
     if (valid) {
       const uint2 ei = my_surv[qhead + (uint32_t)w * CHS + (uint32_t)lane];
       g0 = inst[2 * (size_t)ei.x]; g1 = inst[2 * (size_t)ei.x + 1];
-      idl = ei.y;
-      const uint32_t gid = gauss_of(r, idl);
-      const uint32_t cid = r.colors_per_view ? idl : gid;  // colour row: per view when it comes from SH
+      const uint32_t gid = gauss_of(r, ei.y);
+      gidl = gid;
+      const uint32_t cid = r.colors_per_view ? ei.y : gid;  // colour row: per view when it comes from SH
       if constexpr (!MF && F > 0) {
         if (use_feat) {
 #pragma unroll
@@ -164,9 +164,9 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     // pairs is kept in flight (loaded BD pairs ahead of their use): the whole chunk's operands would not fit the registers.
     constexpr int BD = 4;
     auto load_B = [&](float (&B)[NT > 0 ? NT : 1][BD], int kk) {
-      const uint32_t idA = bcast_lane_u32(idl, 2 * kk), idB = bcast_lane_u32(idl, 2 * kk + 1);
+      const uint32_t gA = bcast_lane_u32(gidl, 2 * kk), gB = bcast_lane_u32(gidl, 2 * kk + 1);
       const uint32_t ent = 2u * kk + (uint32_t)(lane >> 5);
-      const uint32_t gide = gauss_of(r, lane < 32 ? idA : idB);
+      const uint32_t gide = lane < 32 ? gA : gB;
 #pragma unroll
       for (int t = 0; t < (NT > 0 ? NT : 1); t++) {
         const int ch = 32 * t + (lane & 31);
@@ -179,17 +179,28 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       for (int kk = 0; kk < BD; kk++) load_B(Bq, kk);
     }
     MGS_TRACE(3 + 8 * round);
-    // ---- phase A: transmittance product of this chunk ----
-    float tp = 1.0f;
-    for (uint32_t j = 0; j < n_my; j++) {
-      const float ex = bcast_lane(g0.x, (int)j), ey = bcast_lane(g0.y, (int)j);
-      const float cx = bcast_lane(g0.z, (int)j), cy = bcast_lane(g0.w, (int)j), cz = bcast_lane(g1.x, (int)j);
-      const float op = bcast_lane(g1.y, (int)j);
+    // alpha of entry j for my pixel with the reference's two skip tests folded in (forward.cu:345-356): 0 = skipped.
+    // (1 - 0 = 1 exactly, so a skipped entry leaves every product bit for bit alone.)
+    auto alpha_of = [&](int j) -> float {
+      const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
+      const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
+      const float op = bcast_lane(g1.y, j);
       const float dx = ex - p.pxf, dy = ey - p.pyf;
       const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
       const float alpha = fminf(0.99f, op * exp_<FAST>(power));
-      const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
-      tp = skip ? tp : tp * (1.0f - alpha);
+      return ((power > 0.0f) || (alpha < 1.0f / 255.0f)) ? 0.f : alpha;
+    };
+    // ---- phase A: transmittance product of this chunk (four independent alphas in flight, then the product chain) ----
+    float tp = 1.0f;
+    if (n_my == (uint32_t)CHS) {
+#pragma unroll
+      for (int j = 0; j < CHS; j += 4) {
+        const float a0 = alpha_of(j), a1 = alpha_of(j + 1), a2 = alpha_of(j + 2), a3 = alpha_of(j + 3);
+        tp = tp * (1.0f - a0); tp = tp * (1.0f - a1); tp = tp * (1.0f - a2); tp = tp * (1.0f - a3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      for (uint32_t j = 0; j < n_my; j++) tp = tp * (1.0f - alpha_of((int)j));
     }
     MGS_TRACE(4 + 8 * round);
     Tp[round & 1][w][lane] = tp;
@@ -217,17 +228,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       bool done = !live;
       uint32_t last = 0;
       float Tm = T;  // transmittance entering the chunk's second group of 32 (CHS == 64)
-      // one entry of the reference's per-pixel walk (forward.cu:330-380): returns the blend weight alpha * T (0: not blended)
-      auto step = [&](int j) -> float {
-        const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
-        const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
-        const float op = bcast_lane(g1.y, j);
-        const float dx = ex - p.pxf, dy = ey - p.pyf;
-        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-        const float alpha = fminf(0.99f, op * exp_<FAST>(power));
-        const bool skip = (power > 0.0f) || (alpha < 1.0f / 255.0f);
+      // one entry of the reference's per-pixel walk (forward.cu:357-380) given its alpha: returns the blend weight
+      // alpha * T (0: not blended) and advances T / done / last
+      auto advance = [&](int j, float alpha) -> float {
         const float test_T = T * (1.0f - alpha);
-        const bool cand = !done && !skip;
+        const bool cand = !done && alpha > 0.f;
         const bool term = cand && (test_T < 0.0001f);
         done = done || term;
         const bool blend = cand && !term;
@@ -238,32 +243,44 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       };
       bool stop = false;  // wave-uniform: the chunk is exhausted or every pixel has terminated
 #pragma unroll
-      for (int kk = 0; kk < NKK; kk++) {
-        const int j = 2 * kk;
+      for (int kq = 0; kq < NKK / 2; kq++) {  // four entries = two MFMA pairs per step
+        const int j = 4 * kq;
         if (CHS > 32 && j == 32) Tm = T;
         stop = stop || (uint32_t)j >= n_my || ballot(!done) == 0;
-        __builtin_amdgcn_sched_barrier(0);  // one pair at a time: hoisting later pairs' alpha maths only adds live registers
+        __builtin_amdgcn_sched_barrier(0);  // one quad at a time: hoisting later quads' alpha maths only adds live registers
         if (!stop) {
-          float w0 = step(j);
-          float w1 = 0.f;
-          if ((uint32_t)j + 1u < n_my) w1 = step(j + 1);
-          if (ballot(w0 != 0.f || w1 != 0.f) != 0) {
+          float a[4], wq[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) a[u] = ((uint32_t)(j + u) < n_my) ? alpha_of(j + u) : 0.f;  // independent
+#pragma unroll
+          for (int u = 0; u < 4; u++) wq[u] = advance(j + u, a[u]);                                  // the serial chain
+          if (ballot(wq[0] != 0.f || wq[1] != 0.f || wq[2] != 0.f || wq[3] != 0.f) != 0) {
 #pragma unroll
             for (int i = 0; i < NV; i++) {
               const int ci = MF ? i : (i < F ? 3 + i : i - F);  // rowv = [features (F < 16)], r, g, b -> C = r, g, b, features
-              C[ci] += bcast_lane(rowv[i], j) * w0 + bcast_lane(rowv[i], j + 1) * w1;
+#pragma unroll
+              for (int u = 0; u < 4; u++) C[ci] += bcast_lane(rowv[i], j + u) * wq[u];
             }
             if constexpr (MF) {
-              swap32(w0, w1);  // w0: pixels 0..31 x (entry j | j+1), w1: pixels 32..63 x (entry j | j+1)
 #pragma unroll
-              for (int t = 0; t < NT; t++) {
-                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, Bq[t][kk % BD], acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, Bq[t][kk % BD], acc[t][1], 0, 0, 0);
+              for (int h2 = 0; h2 < 2; h2++) {
+                const int kk = 2 * kq + h2;
+                float w0 = wq[2 * h2], w1 = wq[2 * h2 + 1];
+                swap32(w0, w1);  // w0: pixels 0..31 x (entry 2kk | 2kk+1), w1: pixels 32..63 x (entry 2kk | 2kk+1)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                  acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, Bq[t][kk % BD], acc[t][0], 0, 0, 0);
+                  acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, Bq[t][kk % BD], acc[t][1], 0, 0, 0);
+                }
               }
             }
           }
           if constexpr (MF) {
-            if (kk + BD < NKK && (uint32_t)(2 * (kk + BD)) < n_my) load_B(Bq, kk + BD);  // refill the ring slot just used
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {  // refill the two ring slots just used
+              const int kk = 2 * kq + h2;
+              if (kk + BD < NKK && (uint32_t)(2 * (kk + BD)) < n_my) load_B(Bq, kk + BD);
+            }
           }
         }
       }
