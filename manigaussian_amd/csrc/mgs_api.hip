@@ -332,7 +332,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
     StageTimer t(ST_SORT, stream);
-    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, tiles_x, tiles_y, options().seg, host_status, stream),
+    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, tiles_x, tiles_y, options().seg, !dense_render(), host_status, stream),
               "segment-sort binning", a->debug, stream);
   } else {
     { StageTimer t(ST_DUPLICATE, stream);
@@ -350,6 +350,7 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
+  r.rec = g.rec;
   { StageTimer t(ST_RENDER_FWD, stream);
     if (dense_render())
       MGS_STAGE(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, stream), "render forward (dense chunks)",
@@ -518,6 +519,8 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     r.bg = a->background;
     r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
     r.feats = a->language_feature;
+    r.rec = g.rec;
+  r.rec = g.rec;
     StageTimer t(ST_RENDER_BWD, stream);
     if ((CH == 64 || dense_render()) && options().render_mode == 2 && options().bwd_mode == 1)
       MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
@@ -601,6 +604,7 @@ static RenderArgs views_render_args(const MgsRasterArgs* a, const Atlas& at, con
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
   r.feats = a->language_feature;
+  r.rec = g.rec;
   return r;
 }
 }  // namespace mgs
@@ -673,7 +677,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   volatile uint64_t* hs = host_status;
   *hs = kStatusPending;
   { StageTimer t(ST_SORT, stream);
-    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, at.tiles_x, at.tiles_yv * V, options().seg, host_status, stream),
+    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, at.tiles_x, at.tiles_yv * V, options().seg, !dense_render(), host_status, stream),
             "segment-sort binning (views)"); }
   const RenderArgs r = views_render_args(a, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);

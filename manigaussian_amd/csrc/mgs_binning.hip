@@ -348,7 +348,9 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t* a, uint32_t 
 // instance records (gathered early so the gather overlaps the ranking).  One workgroup per segment, two keys per thread.
 // (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores was measured at 45 us
 //  against 19 us for this one at C3: 64 tiles cannot keep 256 CUs busy.)
-template <int SEGN>
+// EMIT: also write the packed instance records next to the ids (the entry-chunk render kernels stream them; the dense
+// kernels gather geom.rec by id instead, which spares this kernel its largest read and write).
+template <int SEGN, bool EMIT>
 __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
                                                                    const uint4* __restrict__ seg_desc,
                                                                    const uint64_t* __restrict__ keys,
@@ -375,11 +377,13 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   }
   // the per-Gaussian record only depends on the id: fetch it now so the gather overlaps the ranking
   float4 r0[2], r1[2];
+  if constexpr (EMIT) {
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
-    const uint32_t id = (tid + e * NT) < cnt ? (uint32_t)key[e] : 0u;
-    r0[e] = rec[2 * (size_t)id];
-    r1[e] = rec[2 * (size_t)id + 1];
+    for (int e = 0; e < 2; e++) {
+      const uint32_t id = (tid + e * NT) < cnt ? (uint32_t)key[e] : 0u;
+      r0[e] = rec[2 * (size_t)id];
+      r1[e] = rec[2 * (size_t)id + 1];
+    }
   }
   if (ns > 1) {
     const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
@@ -418,22 +422,26 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     if (i >= cnt) continue;
     const size_t out = (size_t)start + rank[e];
     point_list[out] = (uint32_t)key[e];
-    inst[2 * out] = r0[e];
-    inst[2 * out + 1] = r1[e];
+    if constexpr (EMIT) { inst[2 * out] = r0[e]; inst[2 * out + 1] = r1[e]; }
   }
 }
 
 template <int SEGN>
-static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
+static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView& im, int R, int T, bool emit_inst,
+                              hipStream_t s) {
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
   hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
                      b.keys_unsorted, b.keys);
-  hipLaunchKernelGGL(bin_merge_emit_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                     b.keys, g.rec, b.point_list, b.inst);
+  if (emit_inst)
+    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, true>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
+                       b.seg_desc, b.keys, g.rec, b.point_list, b.inst);
+  else
+    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, false>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
+                       b.seg_desc, b.keys, g.rec, b.point_list, b.inst);
 }
 
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int tiles_x, int tiles_y, int seg, uint64_t* host_status, hipStream_t s) {
+                              int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
@@ -443,9 +451,9 @@ hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView
                      tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
                      im.ranges, im.seg_base, b.seg_desc);
   switch (seg) {
-    case 512: launch_sort_merge<512>(g, b, im, R, T, s); break;
-    case 1024: launch_sort_merge<1024>(g, b, im, R, T, s); break;
-    default: launch_sort_merge<2048>(g, b, im, R, T, s); break;
+    case 512: launch_sort_merge<512>(g, b, im, R, T, emit_inst, s); break;
+    case 1024: launch_sort_merge<1024>(g, b, im, R, T, emit_inst, s); break;
+    default: launch_sort_merge<2048>(g, b, im, R, T, emit_inst, s); break;
   }
   return hipGetLastError();
 }

@@ -90,7 +90,7 @@ struct ChunkView {
   float* partial;         // [items][3+F][64]
   // survivor-dense chunks (fwd_mode 2): per 8x8 block the in-order list of entries that reach it, kept for the backward
   float* T_mid;           // [items][64]  transmittance after the first 32 survivors of a chunk
-  uint2* surv;            // [4][surv_stride]  block (tile, sub): surv[sub * surv_stride + ranges[tile].x + i] = {entry, id}
+  uint32_t* surv;         // [4][surv_stride]  block (tile, sub): surv[sub * surv_stride + ranges[tile].x + i] = instance id
   size_t surv_stride;     // = capacity of the instance list
   uint32_t* nsurv;        // [T*4]  survivors found by the forward (a prefix of the block's full list)
 };
@@ -162,7 +162,7 @@ inline BinView carve_binning(void* p, int R, int T, int F, int CH, bool legacy, 
     v.q = c.take<float>(items * 64);
     v.partial = c.take<float>(items * (size_t)(3 + F) * 64);
     v.T_mid = c.take<float>(items * 64);
-    v.surv = c.take<uint2>(4 * Ra);
+    v.surv = c.take<uint32_t>(4 * Ra);
     v.surv_stride = Ra;
     v.nsurv = c.take<uint32_t>((size_t)T * 4);
     if (cv) *cv = v;
@@ -233,7 +233,7 @@ hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t
 hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
 // bin_mode 1: scatter -> segment sort -> rank merge + emit (hist is the host copy of im.tile_hist)
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int tiles_x, int tiles_y, int seg, uint64_t* host_status, hipStream_t s);
+                              int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
                             int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);
 hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s);
@@ -252,6 +252,7 @@ struct RenderArgs {
   const float* bg;
   const float* colors;   // [P,3] colors_precomp or geom.rgb
   const float* feats;    // [P,F]
+  const float4* rec;     // geom.rec: [V*P][2] packed per-Gaussian record (the dense render kernels gather it by id)
 };
 hipError_t launch_render_fwd(const RenderArgs& r, const BinView& b, const ImgView& im, float* out_color,
                              float* out_feat, hipStream_t s);

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
                                                           const float* __restrict__ dL_dpix_F, float* __restrict__ acc8,
                                                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat,
                                                           const float* __restrict__ T_mid,
-                                                          const uint2* __restrict__ surv, size_t surv_stride,
+                                                          const uint32_t* __restrict__ surv, size_t surv_stride,
                                                           const uint32_t* __restrict__ nsurv) {
   using C = GmCfg<F>;
   constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
       uint32_t id_e = 0;
       if (lane < ns) {
-        const uint2 ei = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
-        g0 = inst[2 * (size_t)ei.x]; g1 = inst[2 * (size_t)ei.x + 1]; id_e = ei.y;
+        id_e = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
+        g0 = r.rec[2 * (size_t)id_e]; g1 = r.rec[2 * (size_t)id_e + 1];
       }
       wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
       pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);

@@ -42,7 +42,7 @@ template <int F, bool FAST, bool EXACT, int NW, int CHS>
 __global__ void __launch_bounds__(NW * 64)
 coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ inst, float* __restrict__ T_end, float* __restrict__ T_mid,
-                      uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint2* __restrict__ surv,
+                      uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
                       size_t surv_stride, uint32_t* __restrict__ nsurv, float* __restrict__ final_T,
                       uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat) {
   static_assert(CHS == 32 || CHS == 64, "a chunk is one or two 32-lane groups of the Gaussian-major backward");
@@ -71,7 +71,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   const PixBlk p = pix_blk(r, tile, sub, lane);
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
-  uint2* my_surv = surv + (size_t)sub * surv_stride + rng.x;  // this block's compacted list {entry, id}: at most len entries
+  uint32_t* my_surv = surv + (size_t)sub * surv_stride + rng.x;  // this block's compacted list of instance ids: at most len entries
 
   float Tround = 1.0f;
   uint32_t my_vis = 0;
@@ -90,19 +90,22 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     // ---- fill: examine FILLK * FSTEP entries per step until a full round of survivors waits (or the list ends);
     //      survivors go, in list order, to this block's list in memory (read back below and by the backward) ----
     while (qtail - qhead < ROUND && next < rng.y) {
-      uint32_t ee[FILLK], idd[FILLK], rk[FILLK];
+      uint32_t idd[FILLK], rk[FILLK];
       {
         float4 a0[FILLK], a1[FILLK];
 #pragma unroll
         for (int k = 0; k < FILLK; k++) {
-          ee[k] = next + (uint32_t)k * FSTEP + (uint32_t)tid;
-          a0[k] = make_float4(0, 0, 0, 0); a1[k] = make_float4(0, 0, -1.f, -1.f);
-          if (ee[k] < rng.y) { a0[k] = inst[2 * (size_t)ee[k]]; a1[k] = inst[2 * (size_t)ee[k] + 1]; }
+          const uint32_t e = next + (uint32_t)k * FSTEP + (uint32_t)tid;
+          idd[k] = e < rng.y ? point_list[e] : 0xffffffffu;
         }
 #pragma unroll
         for (int k = 0; k < FILLK; k++) {
-          const bool sk = ee[k] < rng.y && cull_ok<EXACT>(a0[k], a1[k], p);
-          idd[k] = sk ? point_list[ee[k]] : 0u;
+          a0[k] = make_float4(0, 0, 0, 0); a1[k] = make_float4(0, 0, -1.f, -1.f);
+          if (idd[k] != 0xffffffffu) { a0[k] = r.rec[2 * (size_t)idd[k]]; a1[k] = r.rec[2 * (size_t)idd[k] + 1]; }
+        }
+#pragma unroll
+        for (int k = 0; k < FILLK; k++) {
+          const bool sk = idd[k] != 0xffffffffu && cull_ok<EXACT>(a0[k], a1[k], p);
           const unsigned long long sm = ballot(sk);
           rk[k] = sk ? (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1ull)) : 0xffffffffu;
           if (lane == 0) cnt[fill & 1][k * NW + w] = (uint32_t)__builtin_popcountll(sm);
@@ -121,7 +124,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
       for (int k = 0; k < FILLK; k++) {
         const uint32_t base = bcast_lane_u32(incl - v, k * NW + w);
-        if (rk[k] != 0xffffffffu) my_surv[qtail + base + rk[k]] = make_uint2(ee[k], idd[k]);
+        if (rk[k] != 0xffffffffu) my_surv[qtail + base + rk[k]] = idd[k];
       }
       qtail += total;
       next += FILLK * FSTEP;
@@ -146,11 +149,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     for (int i = 0; i < NV; i++) rowv[i] = 0.f;
     uint32_t gidl = 0;  // Gaussian (feature row) of my entry
     if (valid) {
-      const uint2 ei = my_surv[qhead + (uint32_t)w * CHS + (uint32_t)lane];
-      g0 = inst[2 * (size_t)ei.x]; g1 = inst[2 * (size_t)ei.x + 1];
-      const uint32_t gid = gauss_of(r, ei.y);
+      const uint32_t id = my_surv[qhead + (uint32_t)w * CHS + (uint32_t)lane];
+      g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
+      const uint32_t gid = gauss_of(r, id);
       gidl = gid;
-      const uint32_t cid = r.colors_per_view ? ei.y : gid;  // colour row: per view when it comes from SH
+      const uint32_t cid = r.colors_per_view ? id : gid;  // colour row: per view when it comes from SH
       if constexpr (!MF && F > 0) {
         if (use_feat) {
 #pragma unroll
