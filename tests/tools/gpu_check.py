@@ -1,11 +1,11 @@
 """GPU diagnostic: self-test, parity vs Oracle B across kernel variants, per-stage timings at the headline
-config.  Run on the GPU box:  python scripts/gpu_check.py [quick]"""
+config.  Run on the GPU box:  python tests/tools/gpu_check.py [quick]"""
 import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 
 from manigaussian_amd import _lib

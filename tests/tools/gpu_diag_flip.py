@@ -1,6 +1,6 @@
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch, util
 from oracle import oracle_b
 for case in [dict(P=6000, F=32, neg=False), dict(P=3000, F=3, M=16, sh_degree=3, unnormalized_rot=True)]:

@@ -1,6 +1,6 @@
 """The reference's own kernels (oracle/_ref, built with hipcc) timed on this MI355X beside the HIP path, same workload.
 
-  python scripts/ref_bench.py [P=100000] [size=128] [steps=200]
+  python tests/tools/ref_bench.py [P=100000] [size=128] [steps=200]
 
 Workloads: BASELINE configs[2] (32 feature channels; the reference rebuilt at that width) and configs[1] (3 channels,
 the stock reference build).  Both sides keep inputs resident and include their per-call zero-fills; the reference side
@@ -15,7 +15,7 @@ import types
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 from manigaussian_amd import synthetic as syn  # noqa: E402

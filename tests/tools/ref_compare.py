@@ -1,6 +1,6 @@
 """Three-way comparison on the GPU box: reference kernels (oracle/_ref) vs Oracle B (CPU) vs the HIP path.
 
-  python scripts/ref_compare.py            # prints per-case errors; test infrastructure, not product
+  python tests/tools/ref_compare.py            # prints per-case errors; test infrastructure, not product
 """
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
