@@ -61,6 +61,26 @@ def _check(case, tight_bins=None):
     return st
 
 
+@pytest.mark.parametrize("F", [3, 32], ids=["valu_blend_f3", "mfma_blend_f32"])
+def test_translucent_scene_walks_many_rounds(F):
+    """Almost transparent Gaussians on a small image: no pixel terminates, so every 8x8 block walks its whole list --
+    thousands of survivors, i.e. several fill steps and several rounds of the dense forward, partial last chunks, and as
+    many chunk records in the backward."""
+    sc, cam, kw, dC, dF = util.scene_case(P=30000, F=F, W=32, H=32)
+    sc["opacities"] = (sc["opacities"] * 0.1).contiguous()
+    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
+    assert st.num_rendered > 4 * 6000 and float(st.array("final_T").min()) > 1e-3  # long lists, nothing terminates
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, True, (0.1, 0.2, 0.3))
+    assert torch.equal(rh, rr)
+    for a, b in ((ch, cr), (fh, fr)):
+        robust, fragile, frac = util.image_errors(a, b, st)
+        assert robust <= IMG_TOL and fragile <= util.FRAGILE_TOL
+    errs, _ = util.grad_errors_split(gh, gr, st)
+    for k, (robust, fragile, mag) in errs.items():
+        assert robust <= GRAD_TOL * mag + 1e-7, f"grad {k}: err {robust:.3e} vs max {mag:.3e}"
+        assert fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7, f"grad {k} (threshold-fragile): {fragile:.3e} vs {mag:.3e}"
+
+
 def test_wave64_primitives_selftest():
     assert _lib.lib().mgs_selftest(None) == 0, _lib.last_error()
 
