@@ -88,7 +88,9 @@ typedef struct MgsRasterArgs {
 int mgs_abi_version(void);
 const char* mgs_last_error(void);
 
-/* Tuning / A-B switches (key names in DESIGN.md); returns <0 for an unknown key. */
+/* Tuning / A-B switches (key names in DESIGN.md section 6); returns <0 for an unknown key.  Process-wide.  Several of them
+ * select the kernels AND the layout of the binning workspace (render_mode, chunk, fwd_mode, dense_variant, bwd_mode,
+ * bin_mode): size the workspace, run the forward and run its backward under the same values. */
 int mgs_set_option(const char* key, int value);
 int mgs_get_option(const char* key);
 
@@ -233,6 +235,10 @@ int mgs_novel_calib_host(int V, const float* c2w, const float* K, int W, int H, 
 int mgs_profile_num_stages(void);
 const char* mgs_profile_stage_name(int stage);
 int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
+
+/* Diagnostic: with mgs_set_option("dbg", 256) the dense render forward stamps s_memtime per (workgroup < 512, wave, phase);
+ * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */
+int mgs_debug_read_trace(unsigned long long* host, size_t count);
 
 /* Device self-test of the wave64 cross-lane primitives used by the render kernels (DPP rotations,
  * v_permlane16/32_swap butterflies).  Returns 0 if every primitive matches its definition. */

@@ -35,7 +35,6 @@ _lib.set_option("dbg", 0)
 L = _lib.lib()
 EV = 24
 buf = np.zeros(512 * 16 * EV, np.uint64)
-L.mgs_debug_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = L.mgs_debug_read_trace(buf.ctypes.data, buf.size)
 assert rc == 0, rc
 t = buf.reshape(512, 16, EV).astype(np.int64)[:256]
