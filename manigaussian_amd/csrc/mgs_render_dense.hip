@@ -8,10 +8,12 @@
 // 34 reach a given 8x8 pixel block (measured at BASELINE configs[2]: mean 33.7, i.e. centred on the 32-lane group size of
 // the Gaussian-major backward, which therefore ran a second, almost empty group for half of the chunks: 65 % lane
 // occupancy).  Here the workgroup first compacts the list, in order, to the entries that reach ITS block (block-wide
-// ballot/popcount scan into an LDS ring of entry indices, also written to memory for the backward), and a chunk is 64
-// consecutive SURVIVORS: every wave blends exactly 64 useful entries per round (perfect balance, half as many per-chunk
-// state records), and the backward gets full groups and no culling of its own.  T_mid (transmittance after the first 32
-// survivors of a chunk) is kept so that the backward's second group starts without a recomputation pass.
+// ballot/popcount scan; the survivors' instance ids go to a per-block list in memory that the rounds and later the backward
+// read), and a chunk is 64 consecutive SURVIVORS: every wave blends exactly 64 useful entries per round (perfect balance,
+// half as many per-chunk state records), and the backward gets full groups and no culling of its own.  Records are gathered
+// from geom.rec by id (L2-resident), so the binning does not emit per-instance record copies for these kernels.  T_mid
+// (transmittance after the first 32 survivors of a chunk) is kept so that the backward's second group starts without a
+// recomputation pass.
 #include "mgs_render_common.h"
 
 namespace mgs {
@@ -32,7 +34,7 @@ __device__ unsigned long long g_trace[512 * 16 * TRACE_EVENTS];
 // waves of the CU.  Here no row goes through LDS:
 //   * F >= 16: the feature contraction  C[pixel][ch] += w[pixel][entry] * feat[entry][ch]  runs on the matrix cores in
 //     exact fp32 (v_mfma_f32_32x32x2_f32 = an fmaf chain).  The B operand is the feature row in its natural layout (lane
-//     (k, ch) loads feat[entry 2kk + k][ch]: one coalesced 128-B row per entry, loaded once per chunk); the A operand is
+//     (k, ch) loads feat[entry 2kk + k][ch]: one coalesced 128-B row per entry, a ring of four pairs in flight); the A operand is
 //     the blend weight the pixel lanes just computed: for an entry pair (j, j+1) ONE v_permlane32_swap turns
 //     (w_j, w_j+1) into the operands of the two pixel tiles (pixels 0..31 / 32..63).  Accumulators leave through one LDS
 //     transposition per chunk.
@@ -41,7 +43,7 @@ __device__ unsigned long long g_trace[512 * 16 * TRACE_EVENTS];
 template <int F, bool FAST, bool EXACT, int NW, int CHS>
 __global__ void __launch_bounds__(NW * 64)
 coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float4* __restrict__ inst, float* __restrict__ T_end, float* __restrict__ T_mid,
+                      float* __restrict__ T_end, float* __restrict__ T_mid,
                       uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
                       size_t surv_stride, uint32_t* __restrict__ nsurv, float* __restrict__ final_T,
                       uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat) {
@@ -377,7 +379,7 @@ static hipError_t dense_F(const RenderArgs& r, const BinView& b, const ImgView& 
   const int grid = ((T + 7) / 8) * 32;
 #define MGS_CFD_(FAST, EXACT, CHS)                                                                                    \
   hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHS>), dim3(grid), dim3(NW * 64), 0, s, r,             \
-                     im.ranges, b.point_list, b.inst, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,           \
+                     im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
                      cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of)
 #define MGS_CFD(FAST, EXACT)                                                                                          \
   do {                                                                                                                \
