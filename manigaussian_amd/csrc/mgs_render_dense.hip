@@ -230,20 +230,21 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       for (int t = 0; t < (NT > 0 ? NT : 1); t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) { acc[t][0][i] = 0.f; acc[t][1][i] = 0.f; }
-      bool done = !live;
+      float alive = live ? 1.0f : 0.0f;  // 0 once the pixel has terminated (kept in a VGPR: no scalar mask algebra per entry)
       uint32_t last = 0;
       float Tm = T;  // transmittance entering the chunk's second group of 32 (CHS == 64)
       // one entry of the reference's per-pixel walk (forward.cu:357-380) given its alpha: returns the blend weight
-      // alpha * T (0: not blended) and advances T / done / last
+      // alpha * T (0: not blended) and advances T / alive / last.  A live pixel always has T >= 1e-4 (it entered so, and
+      // a blend only happens when the new T stays above), hence alpha == 0 (a skipped entry) can never trip the stop
+      // test and needs no test of its own; T * (1 - a) is the reference's test_T bit for bit when a == alpha.
       auto advance = [&](int j, float alpha) -> float {
         const float test_T = T * (1.0f - alpha);
-        const bool cand = !done && alpha > 0.f;
-        const bool term = cand && (test_T < 0.0001f);
-        done = done || term;
-        const bool blend = cand && !term;
-        const float wgt = blend ? alpha * T : 0.f;
-        T = blend ? test_T : T;
-        last = blend ? (uint32_t)j + 1u : last;
+        const bool term = test_T < 0.0001f;
+        const float a = (term ? 0.f : alpha) * alive;  // the entry's alpha if it is blended for this pixel, else 0
+        alive = term ? 0.f : alive;
+        const float wgt = a * T;
+        T = T * (1.0f - a);
+        last = wgt > 0.f ? (uint32_t)j + 1u : last;
         return wgt;
       };
       bool stop = false;  // wave-uniform: the chunk is exhausted or every pixel has terminated
@@ -251,7 +252,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       for (int kq = 0; kq < NKK / 2; kq++) {  // four entries = two MFMA pairs per step
         const int j = 4 * kq;
         if (CHS > 32 && j == 32) Tm = T;
-        stop = stop || (uint32_t)j >= n_my || ballot(!done) == 0;
+        stop = stop || (uint32_t)j >= n_my || ballot(alive != 0.f) == 0;
         __builtin_amdgcn_sched_barrier(0);  // one quad at a time: hoisting later quads' alpha maths only adds live registers
         if (!stop) {
           float a[4], wq[4];
