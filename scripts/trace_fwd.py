@@ -38,22 +38,20 @@ buf = np.zeros(512 * 16 * EV, np.uint64)
 rc = L.mgs_debug_read_trace(buf.ctypes.data, buf.size)
 assert rc == 0, rc
 t = buf.reshape(512, 16, EV).astype(np.int64)[:256]
-t0 = t[:, :, 0].min()
-rel = np.where(t > 0, t - t0, -1)
+# every XCD has its own counter: times are taken relative to each block's own first stamp
+t0 = np.where(t[:, :, 0] > 0, t[:, :, 0], np.iinfo(np.int64).max).min(1)
+rel = np.where(t > 0, t - t0[:, None, None], -1)
 names = {0: "entry", 1: "fill done r0", 2: "list barrier r0", 3: "rows staged r0", 4: "phase A done r0", 5: "Tp barrier r0",
          6: "phase B done r0", 7: "round end r0", 9: "fill done r1", 10: "list barrier r1", 11: "rows r1", 12: "phase A r1",
          13: "Tp barrier r1", 14: "phase B r1", 15: "round end r1", 21: "before final", 22: "image summed", 23: "exit"}
-print(f"variant {variant}; ticks of s_memtime (100 MHz => 10 ns per tick if constant-rate)")
+print(f"variant {variant}; shader-clock cycles (s_memtime) since the block's first stamp; per block the LAST wave counts")
 for e, n in names.items():
-    v = rel[:, :, e]
+    v = rel[:, :, e].max(1)           # the slowest wave of each block reaches the event
     m = v >= 0
     if m.any():
-        print(f"{n:18s} ev {e:2d}: n={int(m.sum()):5d} mean {v[m].mean():8.1f}  p50 {np.median(v[m]):8.1f}  max {v[m].max():8d}")
+        print(f"{n:18s} ev {e:2d}: blocks={int(m.sum()):4d} mean {v[m].mean():9.0f}  p50 {np.median(v[m]):9.0f}  max {v[m].max():8d}")
 ends = rel[:, :, 23].max(1)
-print("block end ticks: min", ends.min(), "mean", ends.mean(), "p90", np.percentile(ends, 90), "max", ends.max())
-starts = rel[:, :, 0].min(1)
-print("block start ticks: max", starts.max())
+print("block duration: min", ends.min(), "mean", int(ends.mean()), "p90", int(np.percentile(ends, 90)), "max", ends.max())
 worst = int(np.argmax(ends))
-print("worst block", worst, "per-event max over waves:", {e: int(rel[worst, :, e].max()) for e in names})
-r2 = (rel[:, :, 9] >= 0).any(1).sum()
-print("blocks with a second round:", int(r2))
+print("slowest block", worst, {e: int(rel[worst, :, e].max()) for e in names})
+print("blocks with a second round:", int((rel[:, :, 9] >= 0).any(1).sum()))
