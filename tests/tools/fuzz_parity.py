@@ -1,0 +1,71 @@
+"""Randomised parity sweep of the HIP path against Oracle B (test infrastructure): python tests/tools/fuzz_parity.py [N] [seed]
+
+Random Gaussian counts, image sizes (not multiples of 16), feature widths, SH degrees, colour sources, opacity scales
+(near-transparent scenes walk whole lists: several fill steps / rounds of the dense forward), cameras and backgrounds.
+Prints one line per case and a summary; exits non-zero on the first violation of the tolerances of tests/test_gpu_parity.py."""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import util  # noqa: E402
+
+IMG_TOL, GRAD_TOL = 1e-4, 1e-3
+
+
+def one(rng, i):
+    F = rng.choice([3, 3, 4, 5, 8, 16, 32, 32, 64])
+    W, H = rng.choice([(8, 8), (17, 33), (32, 32), (40, 72), (64, 64), (100, 52), (128, 128), (200, 120), (256, 256)])
+    P = int(10 ** rng.uniform(0.0, 4.6))
+    if W * H <= 64 * 64:
+        P = min(P, 30000)
+    case = dict(P=P, F=F, W=W, H=H, neg=rng.random() < 0.6, seed=rng.randrange(1000), cam_index=rng.randrange(4),
+                bg=tuple(round(rng.random(), 2) for _ in range(3)))
+    kind = rng.random()
+    if kind < 0.2:
+        case.update(colors_precomp=True)
+    elif kind < 0.4:
+        case.update(M=16, sh_degree=3)
+    elif kind < 0.5:
+        case.update(M=9, sh_degree=2)
+    if rng.random() < 0.15:
+        case.update(include_feature=False)
+    if rng.random() < 0.15:
+        case.update(cov3d=True)
+    if rng.random() < 0.1:
+        case.update(unnormalized_rot=True)
+    op_scale = rng.choice([1.0, 1.0, 1.0, 0.3, 0.1, 3.0])
+    sc, cam, kw, dC, dF = util.scene_case(**case)
+    sc["opacities"] = (sc["opacities"] * op_scale).clamp(max=0.999).contiguous()
+    inc = case.get("include_feature", True)
+    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case["bg"])
+    ok = bool(torch.equal(rh, rr))
+    msgs = [] if ok else ["radii"]
+    for nm, a, b in [("color", ch, cr)] + ([("feature", fh, fr)] if inc else []):
+        robust, fragile, frac = util.image_errors(a, b, st)
+        if not (robust <= IMG_TOL and fragile <= util.FRAGILE_TOL):
+            ok = False
+            msgs.append(f"{nm} {robust:.2e}/{fragile:.2e}")
+    errs, _ = util.grad_errors_split(gh, gr, st)
+    for k, (robust, fragile, mag) in errs.items():
+        if not (robust <= GRAD_TOL * mag + 1e-7 and fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7):
+            ok = False
+            msgs.append(f"grad {k} {robust:.2e}/{fragile:.2e} of {mag:.2e}")
+    print(f"{'OK ' if ok else 'BAD'} #{i} R={st.num_rendered} op*{op_scale} {case} {' | '.join(msgs)}", flush=True)
+    return ok
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = sum(0 if one(rng, i) else 1 for i in range(n))
+    print(f"{n - bad}/{n} cases within tolerance")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
