@@ -48,10 +48,15 @@ __device__ __forceinline__ ViewCov view_cov(V3 mean, const float* __restrict__ v
   o.tx = tx; o.ty = ty; o.tz = tz;
   const float j00 = fx / tz, j02 = -(fx * tx) / (tz * tz);
   const float j11 = fy / tz, j12 = -(fy * ty) / (tz * tz);
+  // T = W * J as glm evaluates it (forward.cu:90-100): every element is the left-to-right sum of three products, J's
+  // zeros included.  The zero terms change no value by themselves, but they decide which product the compiler fuses into an
+  // FMA and which one it rounds first; keeping the reference's expression shape keeps its rounding (a 1-ulp difference in
+  // the 2-D covariance is enough to move ceil(3 sqrt(lambda)) or an alpha across 1/255).
+  const float zero = 0.0f;
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    o.a[r] = vm[4 * r + 0] * j00 + vm[4 * r + 2] * j02;
-    o.b[r] = vm[4 * r + 1] * j11 + vm[4 * r + 2] * j12;
+    o.a[r] = vm[4 * r + 0] * j00 + vm[4 * r + 1] * zero + vm[4 * r + 2] * j02;
+    o.b[r] = vm[4 * r + 0] * zero + vm[4 * r + 1] * j11 + vm[4 * r + 2] * j12;
   }
   return o;
 }
@@ -65,9 +70,10 @@ __device__ __forceinline__ void cov2d_from(const ViewCov& vc, const float* c6, f
     Va[i] = V[i][0] * vc.a[0] + V[i][1] * vc.a[1] + V[i][2] * vc.a[2];
     Vb[i] = V[i][0] * vc.b[0] + V[i][1] * vc.b[1] + V[i][2] * vc.b[2];
   }
-  c00 = vc.a[0] * Va[0] + vc.a[1] * Va[1] + vc.a[2] * Va[2];
-  c01 = vc.b[0] * Va[0] + vc.b[1] * Va[1] + vc.b[2] * Va[2];
-  c11 = vc.b[0] * Vb[0] + vc.b[1] * Vb[1] + vc.b[2] * Vb[2];
+  // cov = (T^T Vrk^T) T (forward.cu:107): cov[0][1], the entry the reference returns as cov.y, is (V b) . a
+  c00 = Va[0] * vc.a[0] + Va[1] * vc.a[1] + Va[2] * vc.a[2];
+  c01 = Vb[0] * vc.a[0] + Vb[1] * vc.a[1] + Vb[2] * vc.a[2];
+  c11 = Vb[0] * vc.b[0] + Vb[1] * vc.b[1] + Vb[2] * vc.b[2];
 }
 
 // Rstd[i][k]: rows as written in forward.cu:135-139 (glm column i), quaternion (r,x,y,z) NOT normalised.

@@ -81,6 +81,18 @@ def test_translucent_scene_walks_many_rounds(F):
         assert fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7, f"grad {k} (threshold-fragile): {fragile:.3e} vs {mag:.3e}"
 
 
+def test_randomised_sweep_fixed_seed():
+    """24 cases of tests/tools/fuzz_parity.py (random sizes, feature widths, colour sources, opacity scales, cameras)."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = random.Random(7)
+    assert all([fz.one(rng, i) for i in range(24)])
+
+
 def test_wave64_primitives_selftest():
     assert _lib.lib().mgs_selftest(None) == 0, _lib.last_error()
 
