@@ -143,6 +143,7 @@ int mgs_set_option(const char* key, int value) {
   else if (!strcmp(key, "bwd_mode")) o.bwd_mode = value;
   else if (!strcmp(key, "dbg")) o.dbg = value;
   else if (!strcmp(key, "fwd_mode")) o.fwd_mode = value;
+  else if (!strcmp(key, "bin_octaves")) o.bin_octaves = value;
   else if (!strcmp(key, "dense_variant")) o.dense_variant = value;
   else if (!strcmp(key, "gm_waves")) o.gm_waves = value;
   else if (!strcmp(key, "seg")) {
@@ -164,6 +165,7 @@ int mgs_get_option(const char* key) {
   if (!strcmp(key, "bin_mode")) return o.bin_mode;
   if (!strcmp(key, "bwd_mode")) return o.bwd_mode;
   if (!strcmp(key, "fwd_mode")) return o.fwd_mode;
+  if (!strcmp(key, "bin_octaves")) return o.bin_octaves;
   if (!strcmp(key, "dense_variant")) return o.dense_variant;
   if (!strcmp(key, "gm_waves")) return o.gm_waves;
   if (!strcmp(key, "seg")) return o.seg;
@@ -173,7 +175,21 @@ int mgs_get_option(const char* key) {
 
 static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 // segment-sort binning keeps per-tile tables in LDS; larger tile grids take the legacy rocPRIM path
-static bool segsort_binning(int T) { return options().bin_mode == 1 && T <= LDS_TILES; }
+static bool segsort_binning(int T) { return (options().bin_mode == 1 || options().bin_mode == 2) && T <= LDS_TILES; }
+// depth buckets per tile of the segment-sort binning (bin_mode 2; 1 bucket otherwise) and the shift of depth_bucket()
+static void bin_buckets(int T, int* NB, int* bshift) {
+  *NB = 1; *bshift = 0;
+  if (options().bin_mode != 2 || T > LDS_TILES) return;
+  const int nb = bin_buckets_max(T);
+  int lnb = 0, loct = 0;
+  while ((1 << (lnb + 1)) <= nb) lnb++;
+  int oct = options().bin_octaves;
+  if (oct < 1) oct = 1;
+  while ((1 << (loct + 1)) <= oct) loct++;
+  int shift = 23 - (lnb - loct);  // 2^(lnb - loct) buckets per octave of depth
+  if (shift > 31) shift = 31;
+  *NB = nb; *bshift = shift;
+}
 size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
 static int chunk_size();
@@ -250,6 +266,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
   segsort = segsort_binning(p.tiles_x * p.tiles_y);
+  bin_buckets(p.tiles_x * p.tiles_y, &p.NB, &p.bshift);
   MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
@@ -332,7 +349,10 @@ static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, f
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
     StageTimer t(ST_SORT, stream);
-    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, tiles_x, tiles_y, options().seg, !dense_render(), host_status, stream),
+    int NB, bshift;
+    bin_buckets(T, &NB, &bshift);
+    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, NB, bshift, tiles_x, tiles_y, options().seg, !dense_render(),
+                                 host_status, stream),
               "segment-sort binning", a->debug, stream);
   } else {
     { StageTimer t(ST_DUPLICATE, stream);
@@ -661,6 +681,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = p.projmatrix = p.campos = nullptr;
   fill_cams(p.cam, a, V, views);
+  bin_buckets(at.T, &p.NB, &p.bshift);
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -677,7 +698,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   volatile uint64_t* hs = host_status;
   *hs = kStatusPending;
   { StageTimer t(ST_SORT, stream);
-    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, at.tiles_x, at.tiles_yv * V, options().seg, !dense_render(), host_status, stream),
+    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, p.NB, p.bshift, at.tiles_x, at.tiles_yv * V, options().seg,
+                               !dense_render(), host_status, stream),
             "segment-sort binning (views)"); }
   const RenderArgs r = views_render_args(a, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);

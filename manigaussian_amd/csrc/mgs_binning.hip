@@ -165,23 +165,35 @@ hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im,
 __device__ __forceinline__ uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
 // Exclusive scan of v[0..n) (LDS) in place; *total (LDS) receives the sum.  All threads of the block call it.
-// tmp: LDS scratch of blockDim.x entries.  blockDim.x <= 1024.
+// tmp: LDS scratch of >= 128 entries.  blockDim.x <= 1024 (16 waves).
 __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t* total) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = (nt + 63) >> 6;
   const int per = (n + nt - 1) / nt;
   const int b = tid * per, e = min(n, b + per);
   uint32_t sum = 0;
   for (int i = b; i < e; i++) sum += v[i];
-  tmp[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < nt; d <<= 1) {  // Hillis-Steele inclusive scan
-    const uint32_t add = tid >= d ? tmp[tid - d] : 0u;
-    __syncthreads();
-    tmp[tid] += add;
-    __syncthreads();
+  // wave-level inclusive scan of the per-thread sums, wave totals through LDS, one more wave-level scan: three barriers
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+    incl += lane >= d ? up : 0u;
   }
-  uint32_t run = tmp[tid] - sum;  // exclusive prefix of this thread's slice
-  if (tid == nt - 1) *total = tmp[tid];
+  if (lane == 63) tmp[wv] = incl;
+  __syncthreads();
+  if (wv == 0) {
+    const uint32_t w = lane < nw ? tmp[lane] : 0u;
+    uint32_t wi = w;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)wi, d, 64);
+      wi += lane >= d ? up : 0u;
+    }
+    if (lane < nw) tmp[64 + lane] = wi - w;  // exclusive prefix of the wave totals
+    if (lane == nw - 1) *total = wi;
+  }
+  __syncthreads();
+  uint32_t run = tmp[64 + wv] + incl - sum;  // exclusive prefix of this thread's slice
   for (int i = b; i < e; i++) { const uint32_t x = v[i]; v[i] = run; run += x; }
   __syncthreads();
 }
@@ -191,7 +203,9 @@ __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t
 
 // Workgroups [0, nblk) scatter the keys of PRE_BLOCK Gaussians each (the partition the preprocess used);
 // workgroup nblk publishes ranges and the segment table for the next two kernels.
-__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int tiles_x, int nblk, uint32_t seg,
+// T = tiles, NB = depth buckets per tile: S = T * NB sort slices, slice (tile, bucket) = tile * NB + bucket.
+__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int NB, int bshift, int tiles_x, int nblk,
+                                                                uint32_t seg,
                                                                 uint32_t capacity, const uint32_t* __restrict__ flags,
                                                                 uint64_t* host_status,
                                                                 const uint2* __restrict__ rect,
@@ -203,9 +217,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
                                                                 uint32_t* __restrict__ seg_base,
                                                                 uint4* __restrict__ seg_desc) {
   extern __shared__ uint32_t lds_u[];
-  uint32_t* s_start = lds_u;          // [T] exclusive scan of the histogram
-  uint32_t* s_cnt = lds_u + T;        // [T] write cursor of this workgroup inside its reservation
-  uint32_t* s_base = lds_u + 2 * T;   // [T] this workgroup's reserved offset inside the tile slice
+  const int S = T * NB;
+  uint32_t* s_start = lds_u;          // [S] exclusive scan of the histogram
+  uint32_t* s_cnt = lds_u + S;        // [S] write cursor of this workgroup inside its reservation
+  uint32_t* s_base = lds_u + 2 * S;   // [S] this workgroup's reserved offset inside the slice
   __shared__ uint32_t tmp[PRE_BLOCK];
   __shared__ uint32_t total;
   const int tid = threadIdx.x;
@@ -215,35 +230,36 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
     __hip_atomic_store(host_status, ((uint64_t)flags[0] << 32) | R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (R > capacity) {  // the workspace cannot hold the lists: publish "nothing binned", the caller retries
     if (tables) {
-      for (int t = tid; t < T; t += blockDim.x) { ranges[t] = make_uint2(0u, 0u); seg_base[t] = 0u; }
-      if (tid == 0) seg_base[T] = 0u;
+      for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(0u, 0u);
+      for (int t = tid; t < S; t += blockDim.x) seg_base[t] = 0u;
+      if (tid == 0) seg_base[S] = 0u;
     }
     return;
   }
-  const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * T;
-  for (int t = tid; t < T; t += blockDim.x) {
+  const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * S;
+  for (int t = tid; t < S; t += blockDim.x) {
     s_start[t] = tile_hist[t];
     s_cnt[t] = 0;
-    s_base[t] = tables ? 0u : row[t];  // only entries of tiles this workgroup contributed to are meaningful
+    s_base[t] = tables ? 0u : row[t];  // only entries of slices this workgroup contributed to are meaningful
   }
   __syncthreads();
-  block_exclusive_scan(s_start, T, tmp, &total);
+  block_exclusive_scan(s_start, S, tmp, &total);
   if (tables) {
-    for (int t = tid; t < T; t += blockDim.x) {
-      const uint32_t L = tile_hist[t];
-      ranges[t] = make_uint2(s_start[t], s_start[t] + L);
-      s_base[t] = div_up_u(L, seg);
+    for (int t = tid; t < T; t += blockDim.x) {  // a tile's list = its slices, one after the other
+      const int last = t * NB + NB - 1;
+      ranges[t] = make_uint2(s_start[t * NB], s_start[last] + tile_hist[last]);
     }
+    for (int t = tid; t < S; t += blockDim.x) s_base[t] = div_up_u(tile_hist[t], seg);
     __syncthreads();
-    block_exclusive_scan(s_base, T, tmp, &total);
-    for (int t = tid; t < T; t += blockDim.x) {
+    block_exclusive_scan(s_base, S, tmp, &total);
+    for (int t = tid; t < S; t += blockDim.x) {
       const uint32_t L = tile_hist[t], ns = div_up_u(L, seg), sb = s_base[t];
       const uint32_t seglen = ns ? div_up_u(L, ns) : 0u;
       seg_base[t] = sb;
       for (uint32_t k = 0; k < ns; k++)
         seg_desc[sb + k] = make_uint4(s_start[t] + k * seglen, min(seglen, L - k * seglen), s_start[t], L);
     }
-    if (tid == 0) seg_base[T] = total;
+    if (tid == 0) seg_base[S] = total;
     return;
   }
   // same (view, Gaussian) partition as the forward preprocess: workgroups never straddle views
@@ -256,10 +272,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16);
   const int y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
   if (x1 <= x0 || y1 <= y0) return;
-  const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+  const float depth = depths[idx];
+  const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
+  const int bk = (int)depth_bucket(depth, NB, bshift);
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) {
-      const int t = y * tiles_x + x;
+      const int t = (y * tiles_x + x) * NB + bk;
       const uint32_t slot = s_start[t] + s_base[t] + atomicAdd(&s_cnt[t], 1u);
       keys_unsorted[slot] = key;
     }
@@ -280,7 +298,8 @@ template <int SEGN>
 __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* __restrict__ n_seg,
                                                                 const uint4* __restrict__ seg_desc,
                                                                 const uint64_t* __restrict__ keys_unsorted,
-                                                                uint64_t* __restrict__ keys) {
+                                                                uint64_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ point_list) {
   __shared__ uint64_t sk[SEGN];
   const uint32_t tid = threadIdx.x;
   const int lane = (int)(tid & 63u);
@@ -326,6 +345,11 @@ __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* _
       k1 = up ? hi : lo;
     }
   }
+  if (point_list && cnt == d.w) {  // the slice is this one segment: sorted ids go straight out, the merge kernel skips it
+    if (e0 < cnt) point_list[base + e0] = (uint32_t)k0;
+    if (e0 + 1u < cnt) point_list[base + e0 + 1u] = (uint32_t)k1;
+    return;
+  }
   if (e0 < cnt) keys[base + e0] = k0;
   if (e0 + 1u < cnt) keys[base + e0 + 1u] = k1;
 }
@@ -364,6 +388,7 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   const uint4 d = seg_desc[blockIdx.x];
   if (blockIdx.x >= *n_seg) return;
   const uint32_t cnt = d.y, start = d.z, L = d.w;
+  if (!EMIT && cnt == L) return;  // single-segment slice: bin_segsort_kernel wrote its ids already
   const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);
   const uint32_t self = (d.x - start) / seglen;
   const uint64_t* __restrict__ tk = keys + start;  // the tile's slice
@@ -428,10 +453,10 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
 
 template <int SEGN>
 static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView& im, int R, int T, bool emit_inst,
-                              hipStream_t s) {
+                              hipStream_t s) {  // T: sort slices
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
   hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                     b.keys_unsorted, b.keys);
+                     b.keys_unsorted, b.keys, emit_inst ? nullptr : b.point_list);
   if (emit_inst)
     hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, true>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
                        b.seg_desc, b.keys, g.rec, b.point_list, b.inst);
@@ -441,19 +466,20 @@ static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView
 }
 
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s) {
+                              int NB, int bshift, int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
   const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
   // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
-                     tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
+  const int S = T * NB;  // sort slices
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)S, s, Pg, T, NB,
+                     bshift, tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
                      im.ranges, im.seg_base, b.seg_desc);
   switch (seg) {
-    case 512: launch_sort_merge<512>(g, b, im, R, T, emit_inst, s); break;
-    case 1024: launch_sort_merge<1024>(g, b, im, R, T, emit_inst, s); break;
-    default: launch_sort_merge<2048>(g, b, im, R, T, emit_inst, s); break;
+    case 512: launch_sort_merge<512>(g, b, im, R, S, emit_inst, s); break;
+    case 1024: launch_sort_merge<1024>(g, b, im, R, S, emit_inst, s); break;
+    default: launch_sort_merge<2048>(g, b, im, R, S, emit_inst, s); break;
   }
   return hipGetLastError();
 }

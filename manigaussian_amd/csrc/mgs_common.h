@@ -13,12 +13,23 @@ constexpr int SUB = 8;           // execution granularity: one wave64 per 8x8 pi
 constexpr int SUBS_PER_TILE = 4;
 constexpr int WAVE = 64;
 constexpr int PRE_BLOCK = 1024;   // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
+// Sort slices.  The segment-sort binning sorts "slices" of the instance list independently: one slice per tile (bin_mode 1)
+// or one per (tile, coarse depth bucket) (bin_mode 2: buckets are disjoint depth ranges in increasing order, so a tile's
+// slices concatenated ARE its sorted list, and slices are small enough to be single sort segments -- no merge pass).
+// NB = buckets per tile = the largest power of two with T * NB <= LDS_TILES; tables are always carved for T * NB slices.
+inline int bin_buckets_max(int T);
 constexpr int LDS_TILES = 4096;   // max tiles whose per-tile tables fit the binning kernels' LDS (else: legacy rocPRIM binning)
 
 // ---- workspace carving (replaces obtain()/fromChunk, RAST rasterizer_impl.h:19-63) -------------
 constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
 
+inline int bin_buckets_max(int T) {
+  int nb = 1;
+  while (T > 0 && (long long)T * nb * 2 <= 4096 && nb < 64) nb *= 2;
+  return nb;
+}
+inline int bin_slices_max(int T) { return T * bin_buckets_max(T); }
 struct Carver {
   char* base;
   size_t off;
@@ -111,7 +122,7 @@ inline GeomView carve_geom(void* p, int P, int M, int T, size_t* total) {
   g.tiles_touched = c.take<uint32_t>(Pa);
   g.point_offsets = c.take<uint32_t>(Pa);
   g.flags = c.take<uint32_t>(4);
-  g.blk_base = c.take<uint32_t>(((Pa + PRE_BLOCK - 1) / PRE_BLOCK) * (size_t)(T > 0 && T <= LDS_TILES ? T : 0) + 1);
+  g.blk_base = c.take<uint32_t>(((Pa + PRE_BLOCK - 1) / PRE_BLOCK) * (size_t)(T > 0 && T <= LDS_TILES ? bin_slices_max(T) : 0) + 1);
   g.scan_temp_bytes = scan_temp_bytes((int)Pa);
   g.scan_temp = c.take<char>(g.scan_temp_bytes);
   (void)M;
@@ -127,11 +138,12 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.final_T = c.take<float>(N ? N : 1);
   v.n_contrib = c.take<uint32_t>(N ? N : 1);
   v.ranges = c.take<uint2>(T ? T : 1);
-  const size_t nz = (4 + 3 * (T ? T : 1) + 1 + 63) & ~(size_t)63;  // whole 256-B units: one fill kernel, no tail
+  const size_t S = T ? (T <= (size_t)LDS_TILES ? (size_t)bin_slices_max((int)T) : T) : 1;  // sort slices (>= tiles)
+  const size_t nz = (4 + 3 * S + 1 + 63) & ~(size_t)63;  // whole 256-B units: one fill kernel, no tail
   v.flags = c.take<uint32_t>(nz);  // flags | hist | cursor | seg_base, contiguous
   v.tile_hist = v.flags ? v.flags + 4 : nullptr;
-  v.tile_cursor = v.flags ? v.tile_hist + (T ? T : 1) : nullptr;
-  v.seg_base = v.flags ? v.tile_hist + 2 * (T ? T : 1) : nullptr;
+  v.tile_cursor = v.flags ? v.tile_hist + S : nullptr;
+  v.seg_base = v.flags ? v.tile_hist + 2 * S : nullptr;
   v.zero_bytes = nz * sizeof(uint32_t);
   if (total) *total = c.total();
   return v;
@@ -146,7 +158,7 @@ inline BinView carve_binning(void* p, int R, int T, int F, int CH, bool legacy, 
   b.vals_unsorted = c.take<uint32_t>(Ra);
   b.point_list = c.take<uint32_t>(Ra);
   b.inst = c.take<float4>(2 * Ra);
-  b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)T + 2);
+  b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)(T <= LDS_TILES ? bin_slices_max(T) : T) + 2);
   b.sort_temp_bytes = legacy ? sort_temp_bytes((int)Ra) : 0;
   b.sort_temp = c.take<char>(b.sort_temp_bytes);
   if (CH > 0) {  // chunk-parallel render state
@@ -201,6 +213,7 @@ struct Options {
   int dense_variant = 1;   // fwd_mode 2: survivors per chunk: 1 = 64 (two full backward groups), 2 = 32
   int fwd_mode = 2;        // render_mode 2, chunk 64: 2 = survivor-dense chunks + MFMA blend (mgs_render_dense.hip),
                            // 1 = entry chunks, LDS-staged rows (coop_fwd64_kernel), 0 = original
+  int bin_octaves = 4;     // bin_mode 2: the depth buckets span this many octaves from the near plane (0.2)
   int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: legacy rocPRIM scan + radix sort
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
 };
@@ -220,8 +233,9 @@ struct FwdPreArgs {
   int V, Pg, Hp;             // P = V * Pg virtual Gaussians, H = view height, tiles_y = tile rows of ONE view
   int use_cam;               // 1: cameras come from cam[] (the multi-view entry points), 0: from the fields below
   ViewCam cam[MAX_VIEWS];
-  uint32_t* tile_hist;  // [T] instance histogram (zeroed by the caller), or nullptr (legacy binning)
-  uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
+  uint32_t* tile_hist;  // [T * NB] instance histogram per sort slice (zeroed by the caller), or nullptr (legacy binning)
+  uint32_t* blk_base;   // [gridDim][T * NB] (with tile_hist)
+  int NB, bshift;       // depth buckets per tile (1: none) and the shift of depth_bucket()
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
   size_t zero_f4;       // ... in float4 units
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
@@ -233,6 +247,7 @@ hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t
 hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
 // bin_mode 1: scatter -> segment sort -> rank merge + emit (hist is the host copy of im.tile_hist)
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
+                              int NB, int bshift,
                               int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
                             int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);

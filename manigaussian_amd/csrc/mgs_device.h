@@ -17,6 +17,15 @@ __device__ __forceinline__ float dpp_mov(float v) {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Coarse depth bucket of a view-space depth (> 0.2, the near cull): monotone non-decreasing in the depth, so sorting the
+// buckets of a tile one after the other is sorting the tile.  Log-spaced: float bits above those of 0.2f, shifted.
+__device__ __forceinline__ uint32_t depth_bucket(float depth, int NB, int shift) {
+  if (NB <= 1) return 0u;
+  const uint32_t u = __float_as_uint(depth), u0 = 0x3E4CCCCDu;  // bits of 0.2f
+  const uint32_t d = u > u0 ? u - u0 : 0u;
+  return min(d >> shift, (uint32_t)NB - 1u);
+}
+
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ float bcast_lane(float v, int j /*wave-uniform*/) {

@@ -132,10 +132,11 @@ def test_reference_reduction_variant_agrees():
 
 
 _DEFAULTS = dict(render_mode=2, chunk=64, fwd_mode=2, dense_variant=1, bwd_mode=1, gm_waves=16, bin_mode=1, seg=2048,
-                 exact_cull=1, fast_exp=1, tight_bins=1)
+                 bin_octaves=4, exact_cull=1, fast_exp=1, tight_bins=1)
 VARIANTS = {
     "legacy_rocprim_binning": dict(bin_mode=0),
     "segments_512": dict(seg=512), "segments_1024": dict(seg=1024),
+    "depth_bucket_slices": dict(bin_mode=2, seg=512), "depth_bucket_slices_2_octaves": dict(bin_mode=2, bin_octaves=2),
     "dense_chunks_of_32": dict(dense_variant=2),
     "dense_gaussian_major_backward_8_waves": dict(gm_waves=8),
     "entry_chunks_lds_rows": dict(fwd_mode=1),
