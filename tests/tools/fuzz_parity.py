@@ -41,8 +41,36 @@ def one(rng, i):
     sc, cam, kw, dC, dF = util.scene_case(**case)
     sc["opacities"] = (sc["opacities"] * op_scale).clamp(max=0.999).contiguous()
     inc = case.get("include_feature", True)
-    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
     ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case["bg"])
+    from oracle import ref_cuda
+    if F in (3, 32) and ref_cuda.available(F):
+        # the reference's own kernels, built by the same compiler, run on this GPU: no cross-compiler rounding in the hard
+        # decisions (alpha / T thresholds, ceil of the radius, depth ties), so the comparison is tight everywhere
+        cr, fr, rr, gr, R = util.run_reference(sc, kw, dC, dF)
+        ok = bool(torch.equal(rh, rr))
+        msgs = [] if ok else ["radii"]
+        # a 1-ulp difference of a conic or a depth still flips an isolated alpha >= 1/255 / T < 1e-4 decision now and then
+        # (the 2-D covariance here is the reference's algebra, not its exact instruction sequence): all but 0.1 % of the
+        # pixels / Gaussians must agree tightly, the few others within the threshold-flip bound of the oracle tests
+        for nm, a, b in [("color", ch, cr)] + ([("feature", fh, fr)] if inc else []):
+            e = (a - b).abs().max(0)[0].flatten()
+            q = float(torch.quantile(e, 0.999)) if e.numel() > 1000 else float(e.max())
+            if q > 2e-5 or float(e.max()) > util.FRAGILE_TOL:
+                ok = False
+                msgs.append(f"{nm} q99.9 {q:.2e} max {float(e.max()):.2e}")
+        for k, v in gh.items():
+            ref = gr[util.GRAD_KEYS[k]].reshape(v.shape)
+            if ref.numel() == 0 or (k == "language_feature" and not inc):
+                continue
+            e, mag = (v - ref).abs().reshape(v.shape[0], -1).max(1)[0], float(ref.abs().max())
+            q = float(torch.quantile(e, 0.999)) if e.numel() > 1000 else float(e.max())
+            # un-normalised quaternions: the reference's own float atomics wander by ~1e-3 of the maximum there
+            if q > 2e-3 * mag + 1e-7 or float(e.max()) > 5.0 * util.FRAGILE_GRAD_TOL * mag + 1e-7:
+                ok = False
+                msgs.append(f"grad {k} q99.9 {q:.2e} max {float(e.max()):.2e} of {mag:.2e}")
+        print(f"{'OK ' if ok else 'BAD'} #{i} R={R} op*{op_scale} vs reference kernels {case} {' | '.join(msgs)}", flush=True)
+        return ok
+    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
     ok = bool(torch.equal(rh, rr))
     msgs = [] if ok else ["radii"]
     for nm, a, b in [("color", ch, cr)] + ([("feature", fh, fr)] if inc else []):
