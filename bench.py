@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--P", type=int, default=100000)
     ap.add_argument("--F", type=int, default=32)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--views", type=int, default=1, help="views of the Gaussian set each GPU renders per step (> 1: one "
+                    "batched call, SURVEY 8f row 1; the headline config is 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--tight-bins", type=int, default=None)
@@ -117,13 +119,21 @@ def main():
     P, F, W, H = args.P, args.F, args.size, args.size
     sc = syn.make_scene(P, F=F, M=4, seed=0)  # identical on every rank: the replicated Gaussian set
     cams = syn.circle_cameras(max(n_gpus, 8), W, H, negative_focal=True)
-    cam = cams[rank % len(cams)]
+    V = max(1, args.views)
+    my_cams = [cams[(rank * V + i) % len(cams)] for i in range(V)]
+    cam = my_cams[0]
     d_color_h, d_feat_h = syn.make_cotangents(W, H, F, seed=1 + rank)
     params = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     d_color, d_feat = d_color_h.to(dev), d_feat_h.to(dev)
-    settings = GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev))
+    all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in my_cams]
+    settings = all_settings[0]
     rast = GaussianRasterizer(settings)
+    if V > 1:  # one batched call per step: V views of the same Gaussian set, gradients summed over the views on the device
+        from manigaussian_amd import GaussianRasterizerBatch
+        rast_batch = GaussianRasterizerBatch(all_settings)
+        d_color = torch.stack([syn.make_cotangents(W, H, F, seed=1 + rank * V + i)[0] for i in range(V)]).to(dev)
+        d_feat = torch.stack([syn.make_cotangents(W, H, F, seed=1 + rank * V + i)[1] for i in range(V)]).to(dev)
     plist = list(params.values())
     pending = []  # (work handle, gradients) of the all-reduce still in flight
 
@@ -134,9 +144,14 @@ def main():
                 h.wait()
 
     def step():
-        color, feat, radii = rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
-                                  shs=params["shs"], language_feature_precomp=params["language_feature"],
-                                  scales=params["scales"], rotations=params["rotations"])
+        if V > 1:
+            color, feat, radii = rast_batch(params["means3D"], None, params["opacities"], shs=params["shs"],
+                                            language_feature_precomp=params["language_feature"],
+                                            scales=params["scales"], rotations=params["rotations"])
+        else:
+            color, feat, radii = rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                                      shs=params["shs"], language_feature_precomp=params["language_feature"],
+                                      scales=params["scales"], rotations=params["rotations"])
         grads = torch.autograd.grad([color, feat], plist, [d_color, d_feat])
         # N > 1: ONE in-place all-reduce of the allocation all gradients alias, asynchronous on RCCL's stream: it
         # overlaps the next step's forward/backward (which write a fresh allocation); a step's reduced gradients are
@@ -183,40 +198,41 @@ def main():
     _lib.set_option("profile", 0)
     stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.profile_read(reset=True).items()}
 
-    # measured instance count (R) of this rank's view
+    # measured instance count (R) of this rank's view(s): what one launch of the render kernels processes
     from manigaussian_amd import _C
     with torch.no_grad():
         e = torch.empty(0, device=dev)
-        R = _C.rasterize_gaussians(settings.bg, params["means3D"], e, params["language_feature"], params["opacities"],
-                                   params["scales"], params["rotations"], 1.0, e, settings.viewmatrix,
-                                   settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, params["shs"], 1,
-                                   settings.campos, False, False, True)[0]
+        R = sum(_C.rasterize_gaussians(st.bg, params["means3D"], e, params["language_feature"], params["opacities"],
+                                       params["scales"], params["rotations"], 1.0, e, st.viewmatrix, st.projmatrix,
+                                       st.tanfovx, st.tanfovy, H, W, params["shs"], 1, st.campos, False, False,
+                                       True)[0] for st in all_settings)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        value = P * n_gpus * args.steps / elapsed  # one view per GPU per step
+        value = P * V * n_gpus * args.steps / elapsed  # V views per GPU per step (headline: 1)
         bwd_ms, bwd_n = prof["render_bwd"]
         bwd_avg_ms = bwd_ms / max(bwd_n, 1)
-        npix = W * H
+        npix = W * H * V  # pixels one launch covers
         bytes_k8 = R * (112 + 12 * F) + npix * (20 + 4 * F)
         achieved = bytes_k8 / (bwd_avg_ms * 1e-3) / 1e9 if bwd_avg_ms > 0 else 0.0
         M = 4
-        bytes_path = P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)
+        bytes_path = V * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)  # all V views
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",
             "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[2]: {P} Gaussians, {W}x{H}, RGB via SH deg 1 (M=4) + {F}-ch language "
-                                   f"feature, fwd+bwd, 1 view per GPU per step, negative-focal look-at cameras",
-                       "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": 1, "num_rendered_R": int(R),
-                       "R_over_P": R / P, "tight_bins": _lib.get_option("tight_bins"),
+                                   f"feature, fwd+bwd, {V} view{'s (one batched call)' if V > 1 else ''} per GPU per step, "
+                                   f"negative-focal look-at cameras",
+                       "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": V, "num_rendered_R": int(R),
+                       "R_over_P": R / (P * V), "tight_bins": _lib.get_option("tight_bins"),
                        "collective": "1 in-place all-reduce of the flat per-Gaussian gradient buffer" if n_gpus > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "K8 render backward (gm_bwd_kernel)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("gm_bwd_kernel"),
                          "algorithmic_bytes_per_launch": bytes_k8, "avg_launch_ms": bwd_avg_ms, "launches": bwd_n},
-            "path_hbm": {"algorithmic_bytes_per_view": bytes_path,
+            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path,
                          "achieved_GBps": bytes_path * n_gpus / (ms_step * 1e-3) / 1e9,
                          "frac_of_peak": bytes_path / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms": stages,
