@@ -2,8 +2,9 @@
 
 Mirror of agents/manigaussian_bc/gaussian_renderer/__init__.py:17-94 (same signature, same returned dict,
 same choices: sh_degree = 3 unless SH features are given, features L2-normalised with a 1e-12 guard, a
-zeros [N,3] placeholder when no language features are given).  The reference file itself also runs
-unmodified against this repository's `diff_gaussian_rasterization` module (tests/test_integration.py).
+zeros [N,3] placeholder when no language features are given).  The reference file itself is executed
+unmodified against this repository's `diff_gaussian_rasterization` package on the GPU by
+tests/test_integration.py (from a build-time byte copy that is never committed).
 """
 import math
 
