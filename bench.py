@@ -1,64 +1,98 @@
 #!/usr/bin/env python
 """bench.py -- Gaussians rasterized/sec (fwd+bwd) on MI355X, BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank per GPU.)
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c5shape|ref16k|c4] [--mode graph|eager|eager-st]
 
-Workload at N=1 = BASELINE.json configs[2] ("100k Gaussians, 128x128, RGB + 32-ch language feature map,
-1xMI355X"), the configuration the metric string is quoted on (128x128, 32 feat-ch): P=100 000 synthetic
-Gaussians (SURVEY.md 8d statistics), SH degree 1 (M=4), F=32, one look-at view per GPU per step, production
-negative-focal cameras, inputs resident in HBM.  A step = one forward + one backward of the rasterizer
-through the public GaussianRasterizer autograd API (+ one all-reduce of the flat per-Gaussian gradient
-buffer when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
+N > 1 without a launcher: the script re-executes itself under `python -m torch.distributed.run --nproc-per-node N`
+(one rank per GPU, RCCL); under a launcher (RANK / WORLD_SIZE set) it checks WORLD_SIZE == N.
+
+Default workload = BASELINE.json configs[2] ("100k Gaussians, 128x128, RGB + 32-ch language feature map, 1xMI355X"), the
+configuration the metric string is quoted on: P=100 000 synthetic Gaussians (SURVEY.md 8d statistics), SH degree 1 (M=4),
+F=32, one look-at view per GPU per step, production negative-focal cameras, inputs resident in HBM.  A step = one forward
++ one backward of the rasterizer through the public GaussianRasterizer autograd API (+ one all-reduce of the per-Gaussian
+parameter gradients when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
+
+Modes (all three are timed; `value` comes from --mode, default graph):
+  graph     the step is captured once with torch.cuda.graph (the library's forward is asynchronous: no host
+            synchronisation inside) and replayed: what a training loop with a HIP-graphed render step runs;
+  eager     the same Python step called K times, torch's default autograd settings;
+  eager-st  eager with torch.autograd.set_multithreading_enabled(False) (round 1's headline setting).
 
 The JSON line also carries
-  roofline:     the dominant kernel (render backward) timed live with HIP events on its launch stream,
-                achieved = algorithmic bytes (R*(112+12F) + N_pix*(20+4F)) / mean duration,
-                against the 8 TB/s HBM peak; traffic = measured HBM bytes per launch from the committed
-                rocprofv3 PMC passes of this command (profiles/pmc_traffic.json).
-  cpu_baseline: Oracle B (oracle/mgs_oracle.c, a port: the reference has no CPU rasterizer) on the host
-                cores, same workload, a bounded number of fwd+bwd passes.
+  roofline      the dominant kernel (render backward) timed live with HIP events on its launch stream; what bounds it
+                (VALU issue, from the committed counter passes profiles/r02_sq_counters.json, tied to the library's
+                hash) and its HBM line: algorithmic bytes (R*(112+12F) + N_pix*(20+4F)) / duration vs
+                8 TB/s, counter bytes per launch;
+  cpu_baseline  Oracle B (oracle/mgs_oracle.c, a port: the reference has no CPU rasterizer) on the host cores, same
+                workload, a bounded number of fwd+bwd passes.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib  # noqa: E402
-from manigaussian_amd import synthetic as syn  # noqa: E402
-from manigaussian_amd.parallel import all_reduce_grads  # noqa: E402
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_GIPS = 1228.8   # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide)
+MIN_TIMED_MS = 50.0       # never report from less GPU time than this: the timed region is extended instead
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+CONFIGS = {
+    "c3": dict(P=100000, F=32, size=128, views=1, renders=1, label="configs[2]"),
+    "c2": dict(P=100000, F=3, size=128, views=1, renders=1, label="configs[1]"),
+    "c5shape": dict(P=500000, F=32, size=256, views=1, renders=1, label="configs[4] shape, one view per GPU"),
+    "ref16k": dict(P=16384, F=3, size=128, views=1, renders=2,
+                   label="ManiGaussian's own step (neural_rendering.py:386-393): 16 384 Gaussians, 2 renders"),
+    "c4": dict(P=100000, F=32, size=128, views=4, renders=1, deform=True,
+               label="configs[3]: deformation MLP (fp32) + 4 views in one batched call per GPU"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--P", type=int, default=100000)
-    ap.add_argument("--F", type=int, default=32)
-    ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--views", type=int, default=1, help="views of the Gaussian set each GPU renders per step (> 1: one "
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st"])
+    ap.add_argument("--P", type=int, default=None)
+    ap.add_argument("--F", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--views", type=int, default=None, help="views of the Gaussian set each GPU renders per step (> 1: one "
                     "batched call, SURVEY 8f row 1; the headline config is 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-mode", action="store_true", help="time --mode only (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--tight-bins", type=int, default=None)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
                                                       "the N>1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--calibrate", action="store_true", help="counter passes: launch the library's known-instruction-mix "
+                                                             "kernel a few times first (scripts/sq_counters.py checks it)")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, cam, d_color, d_feat, P, max_seconds):
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import torch
+    if not args.one_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds):
     """Oracle B fwd+bwd on the host cores (the checker, timed beside the GPU path; never the product)."""
     from oracle import oracle_b
     oracle_b.build()
@@ -82,28 +116,55 @@ def cpu_baseline(sc, cam, d_color, d_feat, P, max_seconds):
                       f"{best * 1e3:.1f} ms, OpenMP {cores} threads"}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
-    (profiles/pmc_traffic.json, written by scripts/pmc_to_json.py; rocprofv3 cannot run inside the bench)."""
+def lib_hash():
+    """Identity of the kernels being timed: a hash over the library's sources (the .so itself is rebuilt per checkout)."""
+    import glob
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "manigaussian_amd", "csrc", "*.h*")) +
+                       [os.path.join(ROOT, "include", "mgsplat.h")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kernel_substr, so_hash):
+    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r02_sq_counters.json, written by
+    scripts/sq_counters.py from runs of THIS command) -- only if they were collected from the library being timed."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            for k, v in json.load(f)["kernels"].items():
-                if kernel in k:
-                    return v["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        with open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")) as f:
+            j = json.load(f)
+        if j.get("lib_sha256_16") != so_hash:
+            return None, f"profiles/r02_sq_counters.json was collected from library {j.get('lib_sha256_16')}, timing {so_hash}"
+        for k, v in j["kernels"].items():
+            if kernel_substr in k:
+                return v, None
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"no committed counters: {e}"
+    return None, "kernel not in profiles/r02_sq_counters.json"
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args)
+    import torch
+    import torch.distributed as dist
+    from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, check_status
+    from manigaussian_amd import synthetic as syn
+    from manigaussian_amd.parallel import all_reduce_grads, flat_alias
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     if args.one_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -116,129 +177,279 @@ def main():
     if args.tight_bins is not None:
         _lib.set_option("tight_bins", args.tight_bins)
 
-    P, F, W, H = args.P, args.F, args.size, args.size
-    sc = syn.make_scene(P, F=F, M=4, seed=0)  # identical on every rank: the replicated Gaussian set
-    cams = syn.circle_cameras(max(n_gpus, 8), W, H, negative_focal=True)
-    V = max(1, args.views)
-    my_cams = [cams[(rank * V + i) % len(cams)] for i in range(V)]
+    cfg = dict(CONFIGS[args.config])
+    for k in ("P", "F", "size", "views"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    P, F, W, H, V, NR = cfg["P"], cfg["F"], cfg["size"], cfg["size"], max(1, cfg["views"]), cfg["renders"]
+    deform = bool(cfg.get("deform"))
+    M = 4
+    sc = syn.make_scene(P, F=F, M=M, seed=0)  # identical on every rank: the replicated Gaussian set
+    cams = syn.circle_cameras(max(n_gpus * V * NR, 8), W, H, negative_focal=True)
+    my_cams = [cams[(rank * V * NR + i) % len(cams)] for i in range(V * NR)]
     cam = my_cams[0]
     d_color_h, d_feat_h = syn.make_cotangents(W, H, F, seed=1 + rank)
     params = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-    d_color, d_feat = d_color_h.to(dev), d_feat_h.to(dev)
     all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in my_cams]
-    settings = all_settings[0]
-    rast = GaussianRasterizer(settings)
+    rasts = [GaussianRasterizer(s) for s in all_settings]
+    cots = [tuple(t.to(dev) for t in syn.make_cotangents(W, H, F, seed=1 + rank * V * NR + i)) for i in range(V * NR)]
+    plist = list(params.values())
     if V > 1:  # one batched call per step: V views of the same Gaussian set, gradients summed over the views on the device
         from manigaussian_amd import GaussianRasterizerBatch
-        rast_batch = GaussianRasterizerBatch(all_settings)
-        d_color = torch.stack([syn.make_cotangents(W, H, F, seed=1 + rank * V + i)[0] for i in range(V)]).to(dev)
-        d_feat = torch.stack([syn.make_cotangents(W, H, F, seed=1 + rank * V + i)[1] for i in range(V)]).to(dev)
-    plist = list(params.values())
-    pending = []  # (work handle, gradients) of the all-reduce still in flight
+        rast_batch = GaussianRasterizerBatch(all_settings[:V])
+        d_color = torch.stack([c for c, _ in cots[:V]])
+        d_feat = torch.stack([f for _, f in cots[:V]])
+    if deform:  # configs[3]: the deformation field moves the Gaussians before the batched render (scripts/bench_c4.py)
+        from manigaussian_amd.deform import DeformationField
+        g = torch.Generator().manual_seed(3)
+        point_latent = torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
+        z_feature = torch.randn(P, 39, generator=g).to(dev)
+        action = torch.randn(1, 8, generator=g).to(dev)
+        field = DeformationField().to(dev)
+        with torch.no_grad():  # the reference zero-initialises fc_1; give the deltas some life without exploding the scene
+            for p_ in field.parameters():
+                p_.mul_(0.05)
+        plist = list(field.parameters()) + [point_latent]
+        tgt_c, tgt_f = torch.rand(V, 3, H, W, generator=g).to(dev), torch.randn(V, F, H, W, generator=g).to(dev)
 
-    def drain():
-        while pending:
-            h, _ = pending.pop()
-            if h is not None:
-                h.wait()
-
-    def step():
+    def render_once(i):
         if V > 1:
-            color, feat, radii = rast_batch(params["means3D"], None, params["opacities"], shs=params["shs"],
-                                            language_feature_precomp=params["language_feature"],
-                                            scales=params["scales"], rotations=params["rotations"])
-        else:
-            color, feat, radii = rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
-                                      shs=params["shs"], language_feature_precomp=params["language_feature"],
-                                      scales=params["scales"], rotations=params["rotations"])
-        grads = torch.autograd.grad([color, feat], plist, [d_color, d_feat])
-        # N > 1: ONE in-place all-reduce of the allocation all gradients alias, asynchronous on RCCL's stream: it
-        # overlaps the next step's forward/backward (which write a fresh allocation); a step's reduced gradients are
-        # complete when the following step issues its own all-reduce (a trainer's optimizer would wait right there).
-        drain()
-        pending.append((all_reduce_grads(grads, async_op=True), grads))
-        return grads
+            return rast_batch(params["means3D"], None, params["opacities"], shs=params["shs"],
+                              language_feature_precomp=params["language_feature"], scales=params["scales"],
+                              rotations=params["rotations"])
+        return rasts[i](means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
+                        language_feature_precomp=params["language_feature"], scales=params["scales"],
+                        rotations=params["rotations"])
+
+    def compute_step():
+        """forward + backward of this rank's render(s); returns the gradients (views of ONE allocation per render)."""
+        if deform:
+            nxt = field(point_latent, z_feature, params["means3D"].detach(), params["shs"].detach(),
+                        params["rotations"].detach(), params["scales"].detach(), params["opacities"].detach(), action=action)
+            color, feat, _ = rast_batch(nxt["xyz"], None, nxt["opacity"], shs=nxt["sh"],
+                                        language_feature_precomp=params["language_feature"].detach(), scales=nxt["scale"],
+                                        rotations=nxt["rot"])
+            loss = ((color - tgt_c) ** 2).mean() + 0.01 * ((feat - tgt_f) ** 2).mean()
+            return torch.autograd.grad(loss, plist)
+        out = None
+        for i in range(NR):
+            color, feat, radii = render_once(i)
+            dc, df = (d_color, d_feat) if V > 1 else cots[i]
+            gs = torch.autograd.grad([color, feat], plist, [dc, df])
+            out = gs if out is None else out  # NR > 1: the renders are independent; the last ones' gradients stand in
+        return out
+
+    # ---- one "stepper" per mode: step() enqueues a whole step, grads() are the tensors an all-reduce takes ----
+    class Eager:
+        def __init__(self):
+            self.last = None
+
+        def next_slot(self):
+            return None
+
+        def step(self):
+            self.last = compute_step()
+            return self.last
+
+    class Graphed:
+        """The step captured into HIP graphs.  Two graphs with their own output buffers alternate when N > 1 so that one
+        step's all-reduce may overlap the next step's replay."""
+
+        def __init__(self, nbuf):
+            for _ in range(3):  # learn the workspace marks, warm the allocator
+                compute_step()
+                check_status(dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                compute_step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graphs, self.outs, self.i = [], [], 0
+            for _ in range(nbuf):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    o = compute_step()
+                self.graphs.append(g)
+                self.outs.append(o)
+
+        def next_slot(self):
+            return self.i % len(self.graphs)
+
+        def step(self):
+            k = self.i % len(self.graphs)
+            self.i += 1
+            self.graphs[k].replay()
+            self.last = self.outs[k]
+            return self.last
+
+    pending = {}  # gradient buffer -> work handle of its all-reduce still in flight
+
+    def run(stepper, k, collective=True):
+        coll = world > 1 and collective
+        for _ in range(k):
+            slot = stepper.next_slot() if coll else None
+            if coll and slot is not None:
+                h = pending.pop(slot, None)
+                if h is not None:
+                    h.wait()  # the buffer this replay overwrites must have been reduced
+            grads = stepper.step()
+            if coll:
+                # ONE in-place all-reduce of the allocation the parameter gradients alias, asynchronous on RCCL's stream:
+                # it overlaps the next step (which writes another allocation)
+                if slot is None:  # eager: every step has a fresh allocation; at most one all-reduce in flight
+                    for h in pending.values():
+                        if h is not None:
+                            h.wait()
+                    pending.clear()
+                    slot = "eager"
+                pending[slot] = all_reduce_grads(grads, async_op=True)
 
     def sync_all():
-        drain()
+        for h in list(pending.values()):
+            if h is not None:
+                h.wait()
+        pending.clear()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Autograd scheduling knob, results unchanged: run the backward on the calling thread instead of handing it
-    # to the engine's device thread (the hand-off costs ~50-100 us of host time per step on this node, which at
-    # ~0.25 ms per step is not noise).  DESIGN.md section 8.
-    torch.autograd.set_multithreading_enabled(False)
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    _lib.profile_read(reset=True)
-    _lib.set_option("profile", 1)  # two hipEvents per step around the render backward only
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    _lib.set_option("profile", 0)
-    prof = _lib.profile_read(reset=True)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(stepper, k, collective=True):
+        """EXACTLY k steps between two (barrier + synchronize) brackets; max over ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        run(stepper, k, collective)
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    # stage breakdown, untimed extra pass
+    def measure(mode, steps, warmup, collective=True):
+        torch.autograd.set_multithreading_enabled(mode != "eager-st")
+        stepper = Graphed(2 if world > 1 else 1) if mode == "graph" else Eager()
+        run(stepper, warmup, collective)
+        el = timed(stepper, steps, collective)
+        if el * 1e3 < MIN_TIMED_MS:  # too little GPU time for a stable clock: extend the timed region, report what was timed
+            steps = int(steps * MIN_TIMED_MS / (el * 1e3) * 1.2) + 1
+            el = timed(stepper, steps, collective)
+        check_status(dev)
+        torch.autograd.set_multithreading_enabled(True)
+        return el, steps, stepper
+
+    if args.calibrate:
+        sink = torch.empty(256 * 1024, device=dev)
+        for _ in range(3):
+            _lib.check(_lib.lib().mgs_calibration_kernel(1000, sink.data_ptr(), None), "calibration")
+        torch.cuda.synchronize()
+    modes = [args.mode] if args.only_mode else [args.mode] + [m for m in ("graph", "eager", "eager-st") if m != args.mode]
+    results, errors = {}, {}
+    headline_stepper = None
+    _lib.profile_read(reset=True)
+    for m in modes:
+        try:
+            if m == args.mode:
+                _lib.set_option("profile", 1)  # two hipEvents per step around the render backward only
+            el, k, stp = measure(m, args.steps, args.warmup)
+            results[m] = (el, k)
+            if m == args.mode:
+                headline_stepper = stp
+        except Exception as e:  # e.g. a graph capture the runtime refuses: report it, keep the other modes
+            if m == args.mode and m != "graph":
+                raise
+            errors[m] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            if m == args.mode:
+                _lib.set_option("profile", 0)
+                prof = _lib.profile_read(reset=True)
+    mode = args.mode if args.mode in results else next(iter(results))
+    elapsed, steps = results[mode]
+
+    exposed_ms, ar_bytes = None, 0
+    if world > 1:
+        fa = flat_alias(headline_stepper.last) if headline_stepper is not None else None
+        ar_bytes = int(fa.numel() * 4) if fa is not None else int(sum(g.numel() for g in headline_stepper.last) * 4)
+    if world > 1:  # what the collective costs on top of the compute: the same K steps without it
+        el0, k0, _ = measure(mode, steps, 5, collective=False)
+        exposed_ms = max(0.0, elapsed / steps - el0 / k0) * 1e3
+
+    # stage breakdown, untimed extra pass (eager: the stage timers are host-side event records)
     _lib.set_option("profile", 2)
-    n_extra = min(args.steps, 20)
-    for _ in range(n_extra):
-        step()
-    drain()
-    torch.cuda.synchronize()
+    e = Eager()
+    run(e, min(steps, 20), collective=False)
+    sync_all()
     _lib.set_option("profile", 0)
     stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.profile_read(reset=True).items()}
 
     # measured instance count (R) of this rank's view(s): what one launch of the render kernels processes
-    from manigaussian_amd import _C
-    with torch.no_grad():
-        e = torch.empty(0, device=dev)
-        R = sum(_C.rasterize_gaussians(st.bg, params["means3D"], e, params["language_feature"], params["opacities"],
-                                       params["scales"], params["rotations"], 1.0, e, st.viewmatrix, st.projmatrix,
-                                       st.tanfovx, st.tanfovy, H, W, params["shs"], 1, st.campos, False, False,
-                                       True)[0] for st in all_settings)
+    R = 0
+    if not deform:
+        from manigaussian_amd import _C
+        with torch.no_grad():
+            et = torch.empty(0, device=dev)
+            R = sum(_C.rasterize_gaussians(st.bg, params["means3D"], et, params["language_feature"], params["opacities"],
+                                           params["scales"], params["rotations"], 1.0, et, st.viewmatrix, st.projmatrix,
+                                           st.tanfovx, st.tanfovy, H, W, params["shs"], 1, st.campos, False, False,
+                                           True)[0] for st in all_settings[:V])
+    dev_ids = [None] * world
+    if world > 1:
+        dist.all_gather_object(dev_ids, torch.cuda.current_device())
+    else:
+        dev_ids = [torch.cuda.current_device()]
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = P * V * n_gpus * args.steps / elapsed  # V views per GPU per step (headline: 1)
+        ms_step = elapsed / steps * 1e3
+        renders = V * NR
+        value = P * renders * n_gpus * steps / elapsed
         bwd_ms, bwd_n = prof["render_bwd"]
         bwd_avg_ms = bwd_ms / max(bwd_n, 1)
         npix = W * H * V  # pixels one launch covers
         bytes_k8 = R * (112 + 12 * F) + npix * (20 + 4 * F)  # SURVEY.md 8d, K8 rows
         achieved = bytes_k8 / (bwd_avg_ms * 1e-3) / 1e9 if bwd_avg_ms > 0 else 0.0
-        M = 4
         bytes_path = V * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)  # all V views
+        so_hash = lib_hash()
+        cnt, why = committed_counters("gm_bwd_kernel", so_hash)
+        traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
+        roof = {"bound": "valu-issue", "kernel": "K8 render backward (gm_bwd_kernel)", "avg_launch_ms": bwd_avg_ms,
+                "launches": bwd_n,
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bytes_k8, "traffic": traffic},
+                "traffic": traffic, "counters": cnt, "counters_note": why, "lib_sha256_16": so_hash}
+        if cnt and cnt.get("SQ_INSTS_VALU") and bwd_avg_ms > 0:
+            gips = cnt["SQ_INSTS_VALU"] / (bwd_avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s (VALU)",
+                         "frac": gips / VALU_PEAK_GIPS})
+        else:  # no counters for this binary: fall back to the HBM line (the kernel is NOT HBM-bound: see DESIGN.md)
+            roof.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",
-            "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: {P} Gaussians, {W}x{H}, RGB via SH deg 1 (M=4) + {F}-ch language "
-                                   f"feature, fwd+bwd, {V} view{'s (one batched call)' if V > 1 else ''} per GPU per step, "
-                                   f"negative-focal look-at cameras",
-                       "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": V, "num_rendered_R": int(R),
-                       "R_over_P": R / (P * V), "tight_bins": _lib.get_option("tight_bins"),
-                       "collective": "1 in-place all-reduce of the flat per-Gaussian gradient buffer" if n_gpus > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "K8 render backward (gm_bwd_kernel)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("gm_bwd_kernel"),
-                         "algorithmic_bytes_per_launch": bytes_k8, "avg_launch_ms": bwd_avg_ms, "launches": bwd_n},
-            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path,
-                         "achieved_GBps": bytes_path * n_gpus / (ms_step * 1e-3) / 1e9,
-                         "frac_of_peak": bytes_path / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "dtype": "f32", "data": "synthetic", "mode": mode, "steps_requested": args.steps,
+            "config": {"workload": f"{cfg['label']}: {P} Gaussians, {W}x{H}, RGB via SH deg 1 (M=4) + {F}-ch language "
+                                   f"feature, fwd+bwd, {renders} render{'s' if renders > 1 else ''} per GPU per step"
+                                   f"{' (one batched call)' if V > 1 else ''}, negative-focal look-at cameras",
+                       "name": args.config, "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": V,
+                       "renders_per_step_per_gpu": renders, "num_rendered_R": int(R), "R_over_P": R / (P * V),
+                       "tight_bins": _lib.get_option("tight_bins"),
+                       "collective": "1 in-place all-reduce of the per-Gaussian parameter gradients per step, overlapping "
+                                     "the next step" if n_gpus > 1 else "none"},
+            "modes_ms_per_step": {m: el / k * 1e3 for m, (el, k) in results.items()}, "mode_errors": errors or None,
+            "distributed": {"backend": args.backend if world > 1 else None,
+                            "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_ids": dev_ids,
+                            "allreduce_bytes_per_step": ar_bytes,
+                            "allreduce_exposed_ms_per_step": exposed_ms},
+            "roofline": roof,
+            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path * NR,
+                         "achieved_GBps": bytes_path * NR * n_gpus / (ms_step * 1e-3) / 1e9,
+                         "frac_of_peak": bytes_path * NR / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms": stages,
         }
-        if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
+        if not args.no_cpu_baseline and n_gpus == 1 and not deform:
+            out["cpu_baseline"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

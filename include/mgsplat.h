@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 3
+#define MGS_ABI_VERSION 4
 
 /* error codes */
 #define MGS_OK 0
@@ -42,11 +42,27 @@ extern "C" {
 #define MGS_ERR_HIP (-2)           /* a HIP runtime call or (debug=1) a kernel failed */
 #define MGS_ERR_WORKSPACE (-3)     /* a caller-provided workspace is too small */
 #define MGS_ERR_NON_RGB (-4)       /* reference: "For non-RGB, provide precomputed Gaussian colors!" */
-#define MGS_NEED_CAPACITY 1        /* mgs_rasterize_forward: binning workspace smaller than num_rendered needs */
+#define MGS_NEED_CAPACITY 1        /* the binning workspace holds fewer instances / chunk records than this scene needs */
+#define MGS_PENDING 2              /* mgs_forward_result: the device has not reported yet */
 
 #define MGS_MAX_FEATURE_CHANNELS 64
 
 typedef void* mgs_stream_t; /* hipStream_t */
+
+/* Per-call tuning.  Every switch selects another implementation of the same result contract; NONE of them changes the
+ * layout of a workspace, so a forward and its backward may even run under different values.  There is no process-wide
+ * option state: a zero-initialised MgsRasterArgs carries `set == 0`, which means "all defaults" (mgs_options_default). */
+typedef struct MgsOptions {
+  int32_t set;          /* 0: ignore the fields below and use the defaults                                        */
+  int32_t tight_bins;   /* 1*: drop (Gaussian, tile) instances whose alpha >= 1/255 footprint misses the tile      */
+  int32_t fast_exp;     /* 1*: v_exp_f32-based exp in the render kernels (rel. error ~2e-7 |x|); 0: ocml expf      */
+  int32_t exact_cull;   /* 1*: exact ellipse-vs-block test on top of the bounding-box test in the render forward   */
+  int32_t bin_mode;     /* 1*: histogram + scatter + LDS segment sort + rank merge; 0: rocPRIM scan + radix sort   */
+  int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048)                                     */
+  int32_t gm_waves;     /* 16*: waves per workgroup of the render backward (8 or 16)                               */
+  int32_t dbg;          /* 0*: diagnostics of the render forward (256: phase timeline, mgs_debug_read_trace)       */
+} MgsOptions;
+void mgs_options_default(MgsOptions* o);  /* fills every field, set = 1 */
 
 /* Per-view configuration + inputs shared by forward and backward.
  * Mirrors the argument lists of Rasterizer::forward / ::backward (RAST/cuda_rasterizer/rasterizer.h:35-91)
@@ -76,21 +92,30 @@ typedef struct MgsRasterArgs {
   const float* campos;          /* [3]                                                                */
   /* opaque workspaces, caller-allocated device memory (uint8 tensors in the reference) */
   void* geom;    size_t geom_bytes;     /* >= mgs_geom_bytes(P, M, W, H)      */
-  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes(R, W, H, F); forward and backward must pass the SAME size */
+  void* binning; size_t binning_bytes;  /* >= mgs_binning_bytes2(binning_capacity, chunk_pool, W, H, F)                */
   void* img;     size_t img_bytes;      /* >= mgs_img_bytes(W, H)             */
   /* Optional: the accumulator block of a LATER backward (its scratch followed by dL_dcolors and dL_dfeature,
    * contiguous, a multiple of 16 bytes).  Forward: if non-NULL the preprocess kernel zeroes it on the side, so the
    * backward needs no fill.  Backward: accum_prezeroed != 0 promises exactly that (and that nothing touched it since). */
   void* bwd_accum; size_t bwd_accum_bytes;
   int32_t accum_prezeroed;
+  /* How the binning workspace is carved; forward and backward must pass the SAME pair (it is not an option: it describes
+   * the buffer).  binning_capacity = instances it holds (0: the largest count that fits binning_bytes with a worst-case
+   * chunk pool, i.e. a buffer sized by mgs_binning_bytes); chunk_pool = chunk records of the render state (0: the worst
+   * case for that capacity, mgs_chunk_pool_max; a caller that remembers the `chunks_used` of earlier forwards of the same
+   * scene can pass a fraction of it: ~6x less memory at BASELINE configs[2]). */
+  int32_t binning_capacity;
+  int32_t chunk_pool;
+  uint32_t status_tag;     /* low 16 bits are echoed in the status words of an asynchronous forward                    */
+  int32_t async_forward;   /* mgs_rasterize_forward[_views]: 1 = enqueue and return, see below                         */
+  MgsOptions opt;
 } MgsRasterArgs;
 
 int mgs_abi_version(void);
 const char* mgs_last_error(void);
 
-/* Tuning / A-B switches (key names in DESIGN.md section 6); returns <0 for an unknown key.  Process-wide.  Several of them
- * select the kernels AND the layout of the binning workspace (render_mode, chunk, fwd_mode, dense_variant, bwd_mode,
- * bin_mode): size the workspace, run the forward and run its backward under the same values. */
+/* Process-wide DIAGNOSTICS only -- never results, kernels or layouts (those are MgsOptions, per call).  The one key is
+ * "profile": 0 off, 1 hipEvents around the render backward, 2 around every stage (mgs_profile_read). */
 int mgs_set_option(const char* key, int value);
 int mgs_get_option(const char* key);
 
@@ -98,7 +123,9 @@ int mgs_get_option(const char* key);
  * (RAST/cuda_rasterizer/rasterizer_impl.h:65-72, rasterizer_impl.cu:155-194). */
 size_t mgs_geom_bytes(int P, int M, int W, int H);
 size_t mgs_img_bytes(int W, int H);
-size_t mgs_binning_bytes(int R, int W, int H, int F);  /* F = feature channels rendered (0 if none) */
+size_t mgs_binning_bytes(int R, int W, int H, int F);  /* F = feature channels rendered (0 if none); worst-case chunk pool */
+size_t mgs_binning_bytes2(int R, int chunk_pool, int W, int H, int F);  /* explicit pool (0: worst case) */
+int mgs_chunk_pool_max(int R, int W, int H);           /* chunk records of the worst case: every chunk of every 8x8 block */
 size_t mgs_backward_scratch_bytes(int P, int M, int F);
 
 /* Forward, stage 1: preprocess + tile-count scan (K2, K3 of SURVEY.md 2b).
@@ -115,20 +142,33 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
 int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
                                  float* out_color, float* out_feature, mgs_stream_t stream);
 
-/* Fused forward: stage 1 + stage 2 in one call with NO mid-call stream synchronisation (the reference
- * blocks on a cudaMemcpy at rasterizer_impl.cu:284; on MI355X that bubble costs more than the binning).
- * The binning workspace is sized by the CALLER's guess (e.g. the high-water mark of earlier calls):
- * a->binning_bytes = mgs_binning_bytes(capacity, W, H, F).  The layout of a binning workspace is a
- * function of its byte size alone, so the backward needs no capacity argument.
- *   host_status: 8 bytes of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory), 8-byte
- *     aligned, owned by the calling thread; the device reports {flags, num_rendered} through it as soon as
- *     the preprocess has run and the call returns without waiting for the render.  NULL: the call reads
- *     the count back with a blocking copy instead (same results, slower).
- * Returns MGS_OK (images written / enqueued, *num_rendered set) or MGS_NEED_CAPACITY (*num_rendered set,
- * geom + radii valid, images NOT rendered: call mgs_rasterize_forward_render with a binning workspace of
- * at least mgs_binning_bytes(*num_rendered, W, H, F)). */
+/* Fused forward: stage 1 + stage 2 in one call with NO mid-call stream synchronisation (the reference blocks on a
+ * cudaMemcpy at rasterizer_impl.cu:284; on MI355X that bubble costs more than the binning).  The binning workspace is
+ * sized by the CALLER's guess (a->binning_capacity / a->chunk_pool, e.g. the high-water marks of earlier calls).
+ *   host_status: 16 bytes of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory), 8-byte aligned, owned
+ *     by this call until its result has been read; the device reports {tag, flags, num_rendered} through word 0 as soon as
+ *     the preprocess has run and {tag, overflow, chunk records used} through word 1 when the render has finished.  The
+ *     call sets both words to "pending" before enqueueing.  NULL: the call reads the count back with a blocking copy
+ *     instead (same results, slower, no chunk-pool report: a->chunk_pool must then be 0).
+ *   a->async_forward == 0: returns once word 0 has arrived (the render may still be running): MGS_OK (images enqueued,
+ *     *num_rendered set) or MGS_NEED_CAPACITY (*num_rendered set, geom + radii valid, images NOT rendered: call
+ *     mgs_rasterize_forward_render with a binning workspace of at least mgs_binning_bytes(*num_rendered, W, H, F)).
+ *     A chunk-pool overflow (only possible with a->chunk_pool != 0) is reported by mgs_forward_result.
+ *   a->async_forward == 1: enqueues everything and returns MGS_OK at once with *num_rendered = -1: no host-device
+ *     synchronisation at all (the call can be captured into a HIP graph together with its backward).  If the scene outgrew
+ *     the workspace the kernels render nothing valid and say so in the status words: the caller MUST look at
+ *     mgs_forward_result before trusting the images -- at the latest when it next synchronises with the stream.  The
+ *     backward may be enqueued (num_rendered = -1) before the result is known; it then computes on whatever the forward
+ *     left and is equally invalid after an overflow. */
 int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_color, float* out_feature,
                           int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream);
+
+/* Host-side decode of the status words of a forward (no HIP call, never blocks).  `a`: the arguments of that forward
+ * (status_tag, binning_capacity, chunk_pool, binning_bytes and the shape are read).  Returns MGS_PENDING until both words
+ * carry this call's tag; then MGS_OK, MGS_NEED_CAPACITY (instances > capacity, or the chunk pool overflowed: the images
+ * and any backward of that forward are invalid) or MGS_ERR_INVALID_ARG (prefiltered violation).  *num_rendered and
+ * *chunks_used (each optional) receive the counts as soon as their word has arrived (-1 before). */
+int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used);
 
 /* Backward (K8-K10).  Replaces Rasterizer::backward (rasterizer_impl.cu:359-463) and the output
  * allocation of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:167-184).  Every non-NULL output
@@ -138,6 +178,7 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
  *   dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4],
  *   dL_dconic [P,4] (optional, may be NULL; reference keeps it internal).
  * scratch: >= mgs_backward_scratch_bytes(P, M, F) device bytes, contents undefined on entry. */
+/* num_rendered: the forward's count, or -1 if the caller has not looked yet (asynchronous forward). */
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
                            const float* dL_dout_color, const float* dL_dout_feature, float* dL_dmeans2D,
                            float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dfeature,
@@ -149,7 +190,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const i
  * campos / tanfov fields are ignored); images are [V,3,H,W] / [V,F,H,W]; radii, dL_dmeans2D, dL_dconic are [V,P,.];
  * dL_dcolors is [V,P,3] with SH colours (colours differ per view) and [P,3] with colors_precomp; every other gradient is
  * per Gaussian, summed over the views on the device.  Workspaces are sized by the mgs_views_*_bytes functions.
- * host_status is required (see mgs_rasterize_forward).  Needs the default kernels and V * tiles <= 4096, V <= 16. */
+ * host_status is required (see mgs_rasterize_forward; async_forward works the same).  Needs V * tiles <= 4096, V <= 16. */
 typedef struct MgsView {
   float tanfovx, tanfovy;
   const float* viewmatrix;  /* [16] */
@@ -159,9 +200,13 @@ typedef struct MgsView {
 size_t mgs_views_geom_bytes(int P, int M, int W, int H, int V);
 size_t mgs_views_img_bytes(int W, int H, int V);
 size_t mgs_views_binning_bytes(int R, int W, int H, int F, int V);
+size_t mgs_views_binning_bytes2(int R, int chunk_pool, int W, int H, int F, int V);
+int mgs_views_chunk_pool_max(int R, int W, int H, int V);
 size_t mgs_views_backward_scratch_bytes(int P, int M, int F, int V);
 int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t* radii, float* out_color,
                                 float* out_feature, int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream);
+int mgs_forward_result_views(const MgsRasterArgs* a, int32_t V, const uint64_t* host_status, int32_t* num_rendered,
+                             int32_t* chunks_used);  /* mgs_forward_result for a batch of V views */
 int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t num_rendered,
                                  const int32_t* radii, const float* dL_dout_color, const float* dL_dout_feature,
                                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
@@ -236,13 +281,18 @@ int mgs_profile_num_stages(void);
 const char* mgs_profile_stage_name(int stage);
 int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
 
-/* Diagnostic: with mgs_set_option("dbg", 256) the dense render forward stamps s_memtime per (workgroup < 512, wave, phase);
+/* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */
 int mgs_debug_read_trace(unsigned long long* host, size_t count);
 
 /* Device self-test of the wave64 cross-lane primitives used by the render kernels (DPP rotations,
  * v_permlane16/32_swap butterflies).  Returns 0 if every primitive matches its definition. */
 int mgs_selftest(mgs_stream_t stream);
+
+/* Counter calibration (scripts/sq_counters.sh): one workgroup-per-CU launch of a kernel with a KNOWN instruction mix per
+ * wave -- iters x (64 v_fma_f32 + 8 v_mfma_f32_32x32x2_f32 + 4 ds_read_b32) -- so that a rocprofv3 --pmc pass can be
+ * validated against exact counts before its numbers for the render kernels are trusted.  sink: >= 256*1024 floats. */
+int mgs_calibration_kernel(int iters, float* sink, mgs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, _state
 
 _F32 = torch.float32
 
@@ -74,42 +74,43 @@ def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefilt
     a.img, a.img_bytes = _ptr(img), 0 if img is None else img.numel()
 
 
-# Per-device host state of the sync-free forward: one pinned 8-byte status word (the device reports
-# {flags, num_rendered} through it) and the high-water mark of num_rendered per problem shape, which sizes
-# the binning workspace BEFORE the count is known (the reference sizes it after a blocking read-back).
-_DEV_STATE = {}
-_CAPACITY = {}  # device -> {shape key: capacity}; shared by all threads (a stale read only costs one retry)
+class ForwardHandle:
+    """What a forward leaves for its backward: the filled MgsRasterArgs (reused, not rebuilt), the per-call options and
+    the pending device report.  int(handle) blocks until the instance count is known (the reference returns it as an int)."""
+    __slots__ = ("a", "opts", "pending", "R", "keep")
+
+    def __init__(self, a, opts, pending, R, keep=None):
+        self.a, self.opts, self.pending, self.R = a, opts, pending, R
+        self.keep = keep  # the tensors whose addresses `a` holds (converted / padded copies would otherwise be freed)
+
+    def num_rendered_nowait(self) -> int:
+        """The count if the device has reported it, else -1 (never blocks)."""
+        if self.R < 0 and self.pending is not None:
+            self.pending.poll()
+            self.R = self.pending.num_rendered
+        return self.R
+
+    def __int__(self):
+        if self.R < 0 and self.pending is not None:
+            while self.pending.num_rendered < 0 and self.pending.poll() == _lib.MGS_PENDING:
+                pass
+            self.R = self.pending.num_rendered
+        return self.R
+
+    __index__ = __int__
 
 
-def _dev_state(dev):
-    """The status word belongs to ONE in-flight forward: it is per (device, calling thread) -- ctypes drops the
-    GIL during the native call, so two Python threads can be inside mgs_rasterize_forward at once."""
-    import threading
-    key = (dev, threading.get_ident())
-    st = _DEV_STATE.get(key)
-    if st is None:
-        pin = torch.zeros(2, dtype=torch.int64).pin_memory()
-        st = {"status": pin, "status_ptr": pin.data_ptr(), "cap": _CAPACITY.setdefault(dev, {})}
-        _DEV_STATE[key] = st
-    return st
-
-
-def _capacity_guess(st, key, P):
-    cap = st["cap"].get(key)
-    return cap if cap is not None else 4 * P + 4096
-
-
-def _remember_capacity(st, key, R):
-    want = R + R // 4 + 4096  # 25 % head-room over the largest count seen for this shape
-    if st["cap"].get(key, 0) < want:
-        st["cap"][key] = want
+def _capturing() -> bool:
+    return torch.cuda.is_current_stream_capturing()
 
 
 def _grad_layout(L, P, M, F):
-    """Float offsets of the backward's single allocation: [scratch | dL_dcolors | dL_dfeature | means3D | means2D |
-    opacity | cov3D | sh | scales | rotations | pad].  The first three regions are the accumulators."""
+    """Float offsets of the backward's single allocation: [scratch | dL_dcolors | dL_dfeature | means3D | opacity | sh |
+    scales | rotations | cov3D | means2D | pad].  The first three regions are the accumulators; the gradients of the
+    Gaussian PARAMETERS (colours or SH, features, means, opacity, scales, rotations) are contiguous, so one all-reduce
+    over the span they cover (parallel.flat_alias) moves nothing else."""
     scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
-    sizes = [scratch_f, 3 * P, F * P, 3 * P, 3 * P, P, 6 * P, 3 * M * P, 3 * P, 4 * P, 4]
+    sizes = [scratch_f, 3 * P, F * P, 3 * P, P, 3 * M * P, 3 * P, 4 * P, 6 * P, 3 * P, 4]
     accum_bytes = ((scratch_f + 3 * P + F * P) * 4 + 15) // 16 * 16  # may reach into the next, fully rewritten, region
     return sizes, accum_bytes
 
@@ -119,17 +120,20 @@ def rasterize_gaussians(background, means3D, colors, language_feature, opacity, 
                         degree, campos, prefiltered, debug, include_feature):
     """RasterizeGaussiansCUDA (RAST/rasterize_points.cu:35-128).
     Returns (num_rendered, out_color [3,H,W], out_language_feature [F,H,W] or [1], radii [P] int32,
-             geomBuffer, binningBuffer, imgBuffer)."""
-    return _forward(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
-                    cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                    campos, prefiltered, debug, include_feature, False)[:7]
+             geomBuffer, binningBuffer, imgBuffer).  Like the reference this entry point returns the count as an int, i.e.
+    it waits for the preprocess (the autograd path, rasterizer.py, does not)."""
+    out = _forward(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
+                   cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                   campos, prefiltered, debug, include_feature, False, blocking=True)
+    return (int(out[0]),) + out[1:7]
 
 
 def _forward(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier, cov3D_precomp,
              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-             debug, include_feature, want_grad_buffer):
+             debug, include_feature, want_grad_buffer, blocking=False):
     """rasterize_gaussians + (want_grad_buffer) the backward's allocation, whose accumulator block the forward's
-    preprocess kernel zeroes on the side: returns the 7-tuple + (grad_buffer or None,)."""
+    preprocess kernel zeroes on the side: returns (ForwardHandle or int, color, feature, radii, geom, binning, img,
+    grad_buffer or None)."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
@@ -169,16 +173,31 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
             e = torch.empty((0,), **u8)
             return (0, out_color, out_feat, torch.zeros((0,), dtype=torch.int32, device=dev), e, e.clone(), e.clone(),
                     None)
+        st = _state.device_state(dev)
+        capturing = _capturing()
+        if not capturing:
+            st.drain()  # reports of earlier forwards that have arrived: learn their counts, raise if one overflowed
         out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
         out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
             torch.zeros((1,), dtype=_F32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)  # written for every Gaussian by the preprocess
-        st = _dev_state(dev)
         key = (P, W, H, F)
-        cap = _capacity_guess(st, key, P)
+        opts = dict(_lib.DEFAULT_OPTIONS)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        guess = st.guess(key)
+        lazy = (guess is not None and not blocking and not debug and _state.forward_mode() == "async"
+                and opts["bin_mode"] == 1 and T <= 4096)
+        if capturing and not lazy:
+            raise RuntimeError("capturing a rasterizer forward into a HIP graph needs the asynchronous path: run this shape "
+                               "eagerly (twice) first so that its workspace sizes are known, with debug=False")
+        if lazy:
+            cap, pool = guess
+        else:  # blocking path: the chunk pool is the worst case for the capacity (cannot overflow)
+            m = st.marks.get(key)
+            cap, pool = (m[0] + m[0] // 4 + 4096 if m else 4 * P + 4096), 0
         geom = torch.empty((L.mgs_geom_bytes(P, M, W, H),), **u8)
         img = torch.empty((L.mgs_img_bytes(W, H),), **u8)
-        binning = torch.empty((L.mgs_binning_bytes(cap, W, H, F),), **u8)
+        binning = torch.empty((L.mgs_binning_bytes2(cap, pool, W, H, F),), **u8)
         a = _lib.MgsRasterArgs()
         _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
                    scale_modifier=float(scale_modifier), prefiltered=prefiltered, debug=debug,
@@ -186,6 +205,9 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
                    language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
                    cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos,
                    geom=geom, binning=binning, img=img)
+        _lib.fill_options(a, opts)
+        slot_ptr, tag = st.take_slot()
+        a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = cap, pool, tag, 1 if lazy else 0
         grad_buffer = None
         if want_grad_buffer:
             sizes, accum_bytes = _grad_layout(L, P, M, F)
@@ -195,18 +217,31 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         nr = ctypes.c_int32(0)
         feat_ptr = out_feat.data_ptr() if include_feature else None
         rc = L.mgs_rasterize_forward(ctypes.byref(a), radii.data_ptr(), out_color.data_ptr(), feat_ptr,
-                                     ctypes.byref(nr), st["status_ptr"], stream)
+                                     ctypes.byref(nr), slot_ptr, stream)
         R = int(nr.value)
-        if rc == _lib.MGS_NEED_CAPACITY:  # first call for this shape, or the scene grew: bin + render again
-            binning = torch.empty((L.mgs_binning_bytes(R + R // 4 + 4096, W, H, F),), **u8)
-            a.binning, a.binning_bytes = binning.data_ptr(), binning.numel()
+        pending = None
+        if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) first call for this shape, or the scene grew: bin + render again
+            cap = R + R // 4 + 4096
+            binning = torch.empty((L.mgs_binning_bytes2(cap, 0, W, H, F),), **u8)
+            a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning.data_ptr(), binning.numel(), cap, 0
             rc = L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(), feat_ptr,
                                                 stream)
-        _lib.check(rc, "rasterize_gaussians")
-        _remember_capacity(st, key, R)
+            _lib.check(rc, "rasterize_gaussians")
+            st.learn(key, R)
+        else:
+            _lib.check(rc, "rasterize_gaussians")
+            pending = _state.Pending(a, 0, slot_ptr, key, captured=capturing)
+            if capturing:
+                st.captured.append(pending)  # reports at every replay: _state.check_status()
+            else:
+                if R >= 0:
+                    st.learn(key, R)
+                st.pending.append(pending)
+        handle = ForwardHandle(a, opts, pending, R, (background, means3D, sh, colors, language_feature, opacity, scales,
+                                                     rotations, cov3D_precomp, viewmatrix, projmatrix, campos))
     if include_feature and F != F_user:
         out_feat = out_feat[:F_user].contiguous()
-    return R, out_color, out_feat, radii, geom, binning, img, grad_buffer
+    return handle, out_color, out_feat, radii, geom, binning, img, grad_buffer
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, language_feature, scales, rotations,
@@ -226,30 +261,25 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
               viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language_feature, sh, degree, campos,
               geomBuffer, R, binningBuffer, imageBuffer, debug, include_feature, grad_buffer):
     """rasterize_gaussians_backward; grad_buffer = the allocation _forward() handed out (accumulators already
-    zeroed by the forward's preprocess kernel) or None."""
+    zeroed by the forward's preprocess kernel) or None.  R: the forward's ForwardHandle (its MgsRasterArgs is reused;
+    the count may still be unknown) or the count as an int (buffers sized by mgs_binning_bytes)."""
     L = _lib.lib()
     dev = means3D.device
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     include_feature = bool(include_feature)
-    means3D = _f32c(means3D, "means3D", dev)
-    colors = _f32c(colors, "colors_precomp", dev)
-    scales = _f32c(scales, "scales", dev)
-    rotations = _f32c(rotations, "rotations", dev)
-    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp", dev)
-    sh = _f32c(sh, "sh", dev)
     dL_dout_color = _f32c(dL_dout_color, "dL_dout_color", dev)
     F = F_user = 0
     if include_feature:
-        language_feature = _f32c(language_feature, "language_feature_precomp", dev)
         F_user = int(language_feature.size(1))
         F = _padded_F(F_user)
         dL_dout_language_feature = _f32c(dL_dout_language_feature, "dL_dout_language_feature", dev)
         if F != F_user:
-            language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
             dL_dout_language_feature = torch.cat(
                 [dL_dout_language_feature, dL_dout_language_feature.new_zeros((F - F_user, H, W))], 0)
+    handle = R if isinstance(R, ForwardHandle) else None
+    keep = None
     with _on_device(dev):
         if P == 0:
             z = lambda *s_: torch.zeros(s_, dtype=_F32, device=dev)  # noqa: E731
@@ -261,24 +291,42 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
         sizes, _ = _grad_layout(L, P, M, F)
         prezeroed = grad_buffer is not None and grad_buffer.numel() == sum(sizes)
         flat = grad_buffer if prezeroed else torch.empty((sum(sizes),), dtype=_F32, device=dev)
-        (scratch, g_colors, g_feat, g_means3D, g_means2D, g_opacity, g_cov3D, g_sh, g_scales, g_rot,
+        (scratch, g_colors, g_feat, g_means3D, g_opacity, g_sh, g_scales, g_rot, g_cov3D, g_means2D,
          _pad) = flat.split_with_sizes(sizes)
-        a = _lib.MgsRasterArgs()
+        if handle is not None:  # the forward's arguments, as they were (same tensors: they are saved in the autograd ctx)
+            a = handle.a
+            count = handle.num_rendered_nowait()
+        else:
+            means3D = _f32c(means3D, "means3D", dev)
+            colors = _f32c(colors, "colors_precomp", dev)
+            scales = _f32c(scales, "scales", dev)
+            rotations = _f32c(rotations, "rotations", dev)
+            cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp", dev)
+            sh = _f32c(sh, "sh", dev)
+            if include_feature:
+                language_feature = _f32c(language_feature, "language_feature_precomp", dev)
+                if F != F_user:
+                    language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+            keep = (means3D, colors, scales, rotations, cov3D_precomp, sh, language_feature)
+            a = _lib.MgsRasterArgs()
+            _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
+                       scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
+                       include_feature=include_feature, background=_f32c(background, "background", dev),
+                       means3D=means3D, sh=sh, colors=colors, language_feature=language_feature, opacity=None,
+                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                       viewmatrix=_f32c(viewmatrix, "viewmatrix", dev), projmatrix=_f32c(projmatrix, "projmatrix", dev),
+                       campos=_f32c(campos, "campos", dev), geom=geomBuffer, binning=binningBuffer, img=imageBuffer)
+            _lib.fill_options(a)
+            count = int(R)
         a.accum_prezeroed = 1 if prezeroed else 0
-        _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
-                   scale_modifier=float(scale_modifier), prefiltered=False, debug=debug,
-                   include_feature=include_feature, background=_f32c(background, "background", dev),
-                   means3D=means3D, sh=sh, colors=colors, language_feature=language_feature, opacity=None,
-                   scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
-                   viewmatrix=_f32c(viewmatrix, "viewmatrix", dev), projmatrix=_f32c(projmatrix, "projmatrix", dev),
-                   campos=_f32c(campos, "campos", dev), geom=geomBuffer, binning=binningBuffer, img=imageBuffer)
         _lib.check(L.mgs_rasterize_backward(
-            ctypes.byref(a), int(R), radii.data_ptr(), dL_dout_color.data_ptr(),
+            ctypes.byref(a), count, radii.data_ptr(), dL_dout_color.data_ptr(),
             _ptr(dL_dout_language_feature) if include_feature else None, g_means2D.data_ptr(), None,
             g_opacity.data_ptr(), g_colors.data_ptr(), _ptr(g_feat) if include_feature else None,
             g_means3D.data_ptr(), g_cov3D.data_ptr(), _ptr(g_sh), g_scales.data_ptr(), g_rot.data_ptr(),
             scratch.data_ptr(), scratch.numel() * 4, _stream(dev)), "rasterize_gaussians_backward")
         g_feat = g_feat.view(P, F) if include_feature else torch.zeros((1,), dtype=_F32, device=dev)
+    del keep
     if include_feature and F != F_user:
         g_feat = g_feat[:, :F_user].contiguous()
     return (g_means2D.view(P, 3), g_colors.view(P, 3), g_feat, g_opacity.view(P, 1), g_means3D.view(P, 3),

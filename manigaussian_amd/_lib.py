@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -18,8 +18,14 @@ c_sz = ctypes.c_size_t
 # error codes (include/mgsplat.h)
 MGS_OK, MGS_ERR_INVALID_ARG, MGS_ERR_HIP, MGS_ERR_WORKSPACE, MGS_ERR_NON_RGB = 0, -1, -2, -3, -4
 MGS_NEED_CAPACITY = 1
+MGS_PENDING = 2
 
 SUPPORTED_F = (3, 4, 8, 16, 32, 64)
+
+
+class MgsOptions(ctypes.Structure):
+    _fields_ = [("set", c_i32), ("tight_bins", c_i32), ("fast_exp", c_i32), ("exact_cull", c_i32), ("bin_mode", c_i32),
+                ("seg", c_i32), ("gm_waves", c_i32), ("dbg", c_i32)]
 
 
 class MgsRasterArgs(ctypes.Structure):
@@ -33,6 +39,8 @@ class MgsRasterArgs(ctypes.Structure):
         ("geom", c_fp), ("geom_bytes", c_sz), ("binning", c_fp), ("binning_bytes", c_sz),
         ("img", c_fp), ("img_bytes", c_sz),
         ("bwd_accum", c_fp), ("bwd_accum_bytes", c_sz), ("accum_prezeroed", c_i32),
+        ("binning_capacity", c_i32), ("chunk_pool", c_i32), ("status_tag", ctypes.c_uint32), ("async_forward", c_i32),
+        ("opt", MgsOptions),
     ]
 
 
@@ -47,11 +55,21 @@ _EXPORTS = {
     # name: (restype, argtypes)
     "mgs_abi_version": (ctypes.c_int, []),
     "mgs_last_error": (ctypes.c_char_p, []),
+    "mgs_options_default": (None, [ctypes.POINTER(MgsOptions)]),
     "mgs_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "mgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "mgs_geom_bytes": (c_sz, [ctypes.c_int] * 4),
     "mgs_img_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
     "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mgs_binning_bytes2": (c_sz, [ctypes.c_int] * 5),
+    "mgs_chunk_pool_max": (ctypes.c_int, [ctypes.c_int] * 3),
+    "mgs_forward_result": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp, ctypes.POINTER(c_i32),
+                                          ctypes.POINTER(c_i32)]),
+    "mgs_forward_result_views": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp, ctypes.POINTER(c_i32),
+                                                ctypes.POINTER(c_i32)]),
+    "mgs_views_binning_bytes2": (c_sz, [ctypes.c_int] * 6),
+    "mgs_views_chunk_pool_max": (ctypes.c_int, [ctypes.c_int] * 4),
+    "mgs_calibration_kernel": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp]),
     "mgs_backward_scratch_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_rasterize_forward_preprocess": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp,
                                                         ctypes.POINTER(c_i32), c_fp]),
@@ -125,12 +143,38 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what}: {last_error()} (code {rc})")
 
 
+# Per-call tuning switches (MgsOptions): the C ABI has no process-wide option state; this dict is merely the DEFAULT the
+# Python shim copies into every call's MgsRasterArgs.opt (a forward's values travel to its backward in the autograd ctx).
+DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=1, exact_cull=1, bin_mode=1, seg=2048, gm_waves=16, dbg=0)
+
+
 def set_option(key: str, value: int):
-    check(lib().mgs_set_option(key.encode(), int(value)), "mgs_set_option")
+    """"profile": the library's one process-wide DIAGNOSTIC switch (stage timers).  Any other key: the default of the
+    per-call option of that name for calls made from this process afterwards."""
+    if key == "profile":
+        check(lib().mgs_set_option(key.encode(), int(value)), "mgs_set_option")
+    elif key in DEFAULT_OPTIONS:
+        if key == "seg" and int(value) not in (512, 1024, 2048):
+            raise RuntimeError("seg must be 512, 1024 or 2048")
+        DEFAULT_OPTIONS[key] = int(value)
+    else:
+        raise RuntimeError(f"unknown option {key}")
 
 
 def get_option(key: str) -> int:
-    return lib().mgs_get_option(key.encode())
+    if key == "profile":
+        return lib().mgs_get_option(key.encode())
+    return DEFAULT_OPTIONS[key]
+
+
+def fill_options(a, opts=None):
+    """Copy per-call options into a.opt (opts: a dict snapshot, default: DEFAULT_OPTIONS); returns the snapshot."""
+    o = DEFAULT_OPTIONS if opts is None else opts
+    q = a.opt
+    q.set = 1
+    q.tight_bins, q.fast_exp, q.exact_cull, q.bin_mode = o["tight_bins"], o["fast_exp"], o["exact_cull"], o["bin_mode"]
+    q.seg, q.gm_waves, q.dbg = o["seg"], o["gm_waves"], o["dbg"]
+    return o if opts is not None else dict(o)
 
 
 def profile_read(reset: bool = True):

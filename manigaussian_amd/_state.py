@@ -1,0 +1,193 @@
+"""Host-side bookkeeping of the asynchronous forward (include/mgsplat.h: mgs_rasterize_forward with async_forward = 1).
+
+The reference blocks every forward on a cudaMemcpy of `num_rendered` (RAST/cuda_rasterizer/rasterizer_impl.cu:284) because
+its binning buffer is sized from that count.  Here a forward sizes its workspace from what earlier forwards of the same
+shape needed (high-water marks + head-room), enqueues everything and returns; the device reports {instances, chunk records
+used, overflow} through two pinned host words.  This module owns
+
+  * the ring of pinned status slots (one per in-flight forward, tagged so that a stale write is recognisable),
+  * the high-water marks per (device, problem shape),
+  * the list of forwards whose report has not been read yet.
+
+Reports are read lazily and never waited for on the hot path: at the next forward, at a backward, or on
+`check_status()`.  If a scene outgrew its workspace the images (and gradients) of THAT call were incomplete; the first
+later call into this module raises RuntimeError (loud, late) after raising the marks so that a re-run fits.  The first
+forward of a shape, `debug=True` settings and `set_forward_mode("blocking")` take the blocking path, which cannot overflow.
+"""
+import collections
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import _lib
+
+NSLOTS = 1024  # status slots per device (two 64-bit words each); far more than forwards can be in flight
+
+_MODE = os.environ.get("MGS_FORWARD_MODE", "async")  # "async" | "blocking"
+_STATES = {}
+_LOCK = threading.Lock()
+_TAG = [0]
+
+
+def set_forward_mode(mode: str):
+    """"async" (default): steady-state forwards return without any host-device synchronisation; "blocking": every
+    forward waits for the instance count like the reference does."""
+    global _MODE
+    if mode not in ("async", "blocking"):
+        raise ValueError("forward mode is 'async' or 'blocking'")
+    _MODE = mode
+
+
+def forward_mode() -> str:
+    return _MODE
+
+
+class Pending:
+    """One forward whose device report has not been read yet."""
+    __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured")
+
+    def __init__(self, a, V, slot_ptr, key, captured=False):
+        self.a, self.V, self.slot_ptr, self.key = a, V, slot_ptr, key
+        self.num_rendered = self.chunks_used = -1
+        self.rc = _lib.MGS_PENDING
+        self.captured = captured
+
+    def poll(self):
+        """Non-blocking read of the status words; returns the library's code (MGS_PENDING until both words arrived)."""
+        if self.rc != _lib.MGS_PENDING:
+            return self.rc
+        L = _lib.lib()
+        nr, ch = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        if self.V:
+            rc = L.mgs_forward_result_views(ctypes.byref(self.a), self.V, self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch))
+        else:
+            rc = L.mgs_forward_result(ctypes.byref(self.a), self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch))
+        if nr.value >= 0:
+            self.num_rendered = nr.value
+        if ch.value >= 0:
+            self.chunks_used = ch.value
+        if rc != _lib.MGS_PENDING:
+            self.rc = rc
+        return rc
+
+
+class DeviceState:
+    def __init__(self, dev):
+        self.dev = dev
+        self.status = torch.full((2 * NSLOTS,), -1, dtype=torch.int64).pin_memory()
+        self.base_ptr = self.status.data_ptr()
+        self.next_slot = 0
+        self.marks = {}      # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
+        self.pending = collections.deque()
+        self.captured = []   # forwards recorded into HIP graphs: their slots stay reserved, check_status() reads them
+        self.lock = threading.Lock()
+
+    def take_slot(self):
+        """(pointer to two pinned words, tag) for one forward."""
+        with self.lock:
+            reserved = {p.slot_ptr for p in self.captured}
+            for _ in range(NSLOTS):
+                i = self.next_slot
+                self.next_slot = (i + 1) % NSLOTS
+                ptr = self.base_ptr + 16 * i
+                if ptr not in reserved:
+                    break
+            else:
+                raise RuntimeError("all status slots are held by captured graphs")
+        with _LOCK:
+            _TAG[0] = (_TAG[0] + 1) & 0xffff
+            tag = _TAG[0]
+        return ptr, tag
+
+    # ---- high-water marks ---------------------------------------------------------------------------------------
+    def guess(self, key):
+        """(capacity, chunk pool) for an asynchronous forward of this shape, or None if the shape is new."""
+        m = self.marks.get(key)
+        if m is None or m[1] is None:
+            return None
+        return m[0] + m[0] // 4 + 4096, m[1] + m[1] // 2 + 64
+
+    def learn(self, key, R=None, chunks=None, pool_unknown=False):
+        m = self.marks.setdefault(key, [0, None])
+        if R is not None and R > m[0]:
+            m[0] = R
+        if pool_unknown:
+            m[1] = None
+        elif chunks is not None and (m[1] is None or chunks > m[1]):
+            m[1] = chunks
+
+    # ---- reports --------------------------------------------------------------------------------------------------
+    def drain(self, wait=False):
+        """Read every report that has arrived (wait=True: all of them).  Raises if a forward overflowed its workspace."""
+        if not self.pending:
+            return
+        failed = None
+        with self.lock:
+            keep = collections.deque()
+            while self.pending:
+                p = self.pending.popleft()
+                rc = p.poll()
+                while rc == _lib.MGS_PENDING and wait:
+                    rc = p.poll()
+                if rc == _lib.MGS_PENDING:
+                    if len(self.pending) + len(keep) >= NSLOTS // 2:  # the ring would wrap: this one must finish first
+                        torch.cuda.synchronize(self.dev)
+                        rc = p.poll()
+                    else:
+                        keep.append(p)
+                        continue
+                failed = self._account(p, rc) or failed
+            self.pending = keep
+        if failed:
+            raise RuntimeError(failed)
+
+    def _account(self, p, rc):
+        """Fold a finished forward into the marks; returns an error message if it overflowed."""
+        if rc == _lib.MGS_OK:
+            self.learn(p.key, p.num_rendered, p.chunks_used)
+            return None
+        if rc == _lib.MGS_NEED_CAPACITY:
+            over_inst = p.num_rendered > p.a.binning_capacity > 0
+            self.learn(p.key, p.num_rendered if p.num_rendered >= 0 else None, None, pool_unknown=not over_inst)
+            what = (f"{p.num_rendered} (Gaussian, tile) instances > capacity {p.a.binning_capacity}" if over_inst else
+                    f"chunk pool of {p.a.chunk_pool} records")
+            return ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
+                    f"({what}): the images and gradients of THAT call were incomplete.  The marks are raised; re-run the "
+                    "step, or use manigaussian_amd.set_forward_mode('blocking') for scenes that grow abruptly.")
+        return f"rasterizer forward failed: {_lib.last_error()} (code {rc})"
+
+    def check_captured(self):
+        bad = None
+        for p in self.captured:
+            p.rc = _lib.MGS_PENDING
+            rc = p.poll()
+            if rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
+                bad = self._account(p, rc) or bad
+        if bad:
+            raise RuntimeError(bad)
+
+
+def device_state(dev) -> DeviceState:
+    st = _STATES.get(dev)
+    if st is None:
+        with _LOCK:
+            st = _STATES.get(dev)
+            if st is None:
+                st = DeviceState(dev)
+                _STATES[dev] = st
+    return st
+
+
+def check_status(device=None, wait=True):
+    """Read the outstanding forward reports of `device` (default: all devices used so far), waiting for them unless
+    wait=False, and raise if one of them -- or a forward replayed from a captured HIP graph -- overflowed its workspace.
+    A training loop calls this wherever it synchronises anyway (logging a loss, an optimizer step)."""
+    for dev, st in list(_STATES.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        if wait and st.pending:
+            torch.cuda.synchronize(dev)
+        st.drain(wait=wait)
+        st.check_captured()

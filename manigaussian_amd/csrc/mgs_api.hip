@@ -21,8 +21,17 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options& options() {
-  static Options o;
+static int g_profile = 0;  // diagnostics only (mgs_set_option("profile", .)): never results or layouts
+int profile_level() { return g_profile; }
+
+// MgsOptions of a call with the defaults filled in
+static Options options_of(const MgsRasterArgs* a) {
+  Options o;
+  if (a && a->opt.set) {
+    o.tight_bins = a->opt.tight_bins; o.fast_exp = a->opt.fast_exp; o.exact_cull = a->opt.exact_cull;
+    o.bin_mode = a->opt.bin_mode ? 1 : 0; o.gm_waves = a->opt.gm_waves == 8 ? 8 : 16; o.dbg = a->opt.dbg;
+    o.seg = (a->opt.seg == 512 || a->opt.seg == 1024) ? a->opt.seg : 2048;
+  }
   return o;
 }
 
@@ -55,7 +64,7 @@ static Profiler& profiler() { static Profiler p; return p; }
 struct StageTimer {  // RAII: records start now, stop at scope exit
   int stage; hipStream_t stream; hipEvent_t e0 = nullptr, e1 = nullptr;
   StageTimer(int st, hipStream_t s) : stage(st), stream(s) {
-    const int lvl = options().profile;
+    const int lvl = g_profile;
     if (lvl == 0 || (lvl == 1 && st != ST_RENDER_BWD)) return;
     Profiler& p = profiler();
     std::lock_guard<std::mutex> lk(p.mu);
@@ -130,105 +139,46 @@ extern "C" {
 int mgs_abi_version(void) { return MGS_ABI_VERSION; }
 const char* mgs_last_error(void) { return g_err; }
 
+void mgs_options_default(MgsOptions* o) {
+  if (!o) return;
+  const Options d;
+  o->set = 1; o->tight_bins = d.tight_bins; o->fast_exp = d.fast_exp; o->exact_cull = d.exact_cull;
+  o->bin_mode = d.bin_mode; o->seg = d.seg; o->gm_waves = d.gm_waves; o->dbg = d.dbg;
+}
+
 int mgs_set_option(const char* key, int value) {
-  Options& o = options();
-  if (!strcmp(key, "tight_bins")) o.tight_bins = value;
-  else if (!strcmp(key, "bwd_reduce")) o.bwd_reduce = value;
-  else if (!strcmp(key, "fast_exp")) o.fast_exp = value;
-  else if (!strcmp(key, "profile")) o.profile = value;
-  else if (!strcmp(key, "render_mode")) o.render_mode = value;
-  else if (!strcmp(key, "chunk")) o.chunk = value;
-  else if (!strcmp(key, "exact_cull")) o.exact_cull = value;
-  else if (!strcmp(key, "bin_mode")) o.bin_mode = value;
-  else if (!strcmp(key, "bwd_mode")) o.bwd_mode = value;
-  else if (!strcmp(key, "dbg")) o.dbg = value;
-  else if (!strcmp(key, "fwd_mode")) o.fwd_mode = value;
-  else if (!strcmp(key, "bin_octaves")) o.bin_octaves = value;
-  else if (!strcmp(key, "dense_variant")) o.dense_variant = value;
-  else if (!strcmp(key, "gm_waves")) o.gm_waves = value;
-  else if (!strcmp(key, "seg")) {
-    if (value != 512 && value != 1024 && value != 2048) { set_error("seg must be 512, 1024 or 2048"); return MGS_ERR_INVALID_ARG; }
-    o.seg = value;
-  }
-  else { set_error("unknown option %s", key); return MGS_ERR_INVALID_ARG; }
-  return MGS_OK;
+  if (!strcmp(key, "profile")) { g_profile = value; return MGS_OK; }
+  set_error("unknown option %s (tuning switches are per call: MgsRasterArgs.opt)", key);
+  return MGS_ERR_INVALID_ARG;
 }
 int mgs_get_option(const char* key) {
-  Options& o = options();
-  if (!strcmp(key, "tight_bins")) return o.tight_bins;
-  if (!strcmp(key, "bwd_reduce")) return o.bwd_reduce;
-  if (!strcmp(key, "fast_exp")) return o.fast_exp;
-  if (!strcmp(key, "profile")) return o.profile;
-  if (!strcmp(key, "render_mode")) return o.render_mode;
-  if (!strcmp(key, "chunk")) return o.chunk;
-  if (!strcmp(key, "exact_cull")) return o.exact_cull;
-  if (!strcmp(key, "bin_mode")) return o.bin_mode;
-  if (!strcmp(key, "bwd_mode")) return o.bwd_mode;
-  if (!strcmp(key, "fwd_mode")) return o.fwd_mode;
-  if (!strcmp(key, "bin_octaves")) return o.bin_octaves;
-  if (!strcmp(key, "dense_variant")) return o.dense_variant;
-  if (!strcmp(key, "gm_waves")) return o.gm_waves;
-  if (!strcmp(key, "seg")) return o.seg;
+  if (!strcmp(key, "profile")) return g_profile;
   set_error("unknown option %s", key);
   return MGS_ERR_INVALID_ARG;
 }
 
 static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
-// segment-sort binning keeps per-tile tables in LDS; larger tile grids take the legacy rocPRIM path
-static bool segsort_binning(int T) { return (options().bin_mode == 1 || options().bin_mode == 2) && T <= LDS_TILES; }
-// depth buckets per tile of the segment-sort binning (bin_mode 2; 1 bucket otherwise) and the shift of depth_bucket()
-static void bin_buckets(int T, int* NB, int* bshift) {
-  *NB = 1; *bshift = 0;
-  if (options().bin_mode != 2 || T > LDS_TILES) return;
-  const int nb = bin_buckets_max(T);
-  int lnb = 0, loct = 0;
-  while ((1 << (lnb + 1)) <= nb) lnb++;
-  int oct = options().bin_octaves;
-  if (oct < 1) oct = 1;
-  while ((1 << (loct + 1)) <= oct) loct++;
-  int shift = 23 - (lnb - loct);  // 2^(lnb - loct) buckets per octave of depth
-  if (shift > 31) shift = 31;
-  *NB = nb; *bshift = shift;
-}
+// segment-sort binning keeps per-tile tables in LDS; larger tile grids take the rocPRIM path
+static bool segsort_binning(const Options& o, int T) { return o.bin_mode == 1 && T <= LDS_TILES; }
 size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
-static int chunk_size();
-// survivor-dense chunks (mgs_render_dense.hip + the DENSE Gaussian-major backward): the default pair of render kernels
-static bool dense_render() {
-  const Options& o = options();
-  return o.render_mode == 2 && chunk_size() == 64 && o.fwd_mode == 2 && o.bwd_mode == 1;
-}
-static int carve_chunk();
-static int chunk_size() {  // 0 when the chunk-parallel render is off
-  const Options& o = options();
-  if (o.render_mode != 1 && o.render_mode != 2) return 0;
-  int ch = o.chunk < 64 ? 64 : o.chunk;
-  return (ch + 63) / 64 * 64;
-}
-// chunk size the per-chunk render state is laid out for: SURVIVORS with the dense kernels, `chunk` entries otherwise
-static int carve_chunk() { return dense_render() ? (options().dense_variant == 2 ? 32 : 64) : chunk_size(); }
-size_t mgs_binning_bytes(int R, int W, int H, int F) {
+static size_t binning_bytes_T(int R, int pool, int T, int F) {
   size_t t;
-  carve_binning(nullptr, R, num_tiles(W, H), F, carve_chunk(), !segsort_binning(num_tiles(W, H)), nullptr, &t);
+  carve_binning(nullptr, R, T, F, pool > 0 ? (uint32_t)pool : 0u, nullptr, &t);
   return t;
 }
+size_t mgs_binning_bytes2(int R, int chunk_pool, int W, int H, int F) { return binning_bytes_T(R, chunk_pool, num_tiles(W, H), F); }
+size_t mgs_binning_bytes(int R, int W, int H, int F) { return binning_bytes_T(R, 0, num_tiles(W, H), F); }
+int mgs_chunk_pool_max(int R, int W, int H) { return (int)chunk_pool_max(R > 0 ? (size_t)R : 1, num_tiles(W, H)); }
 size_t mgs_backward_scratch_bytes(int P, int M, int F) { size_t t; carve_bwd(nullptr, P, M, F, &t); return t; }
 
 static const uint64_t kStatusPending = ~0ull;
-static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy);
-// Largest instance capacity whose binning layout fits `bytes`: the layout of a binning workspace is a function
-// of its SIZE, so forward and backward agree on it whatever count the caller passes.
-static int binning_capacity(size_t bytes, int T, int F, bool legacy) {
-  struct Memo { size_t bytes; int T, F, ch, legacy, cap; };
-  static thread_local Memo memo = {0, -1, -1, -1, -1, -1};
-  if (memo.bytes == bytes && memo.T == T && memo.F == F && memo.ch == carve_chunk() && memo.legacy == (int)legacy)
-    return memo.cap;
-  const int cap_ = binning_capacity_uncached(bytes, T, F, legacy);
-  memo = {bytes, T, F, carve_chunk(), (int)legacy, cap_};
-  return cap_;
-}
-static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy) {
-  auto need = [&](int R) { size_t t; carve_binning(nullptr, R, T, F, carve_chunk(), legacy, nullptr, &t); return t; };
+
+// How the caller carved the binning workspace: {instances it holds, chunk records}.  Explicit (binning_capacity > 0) or,
+// for a buffer sized by mgs_binning_bytes, the largest count that fits with a worst-case pool.
+struct BinShape { int cap; uint32_t pool; };
+static int binning_capacity_uncached(size_t bytes, int T, int F) {
+  auto need = [&](int R) { return binning_bytes_T(R, 0, T, F); };
   if (need(0) > bytes) return -1;
   int lo = 0, hi = 1;
   while (hi < (1 << 30) && need(hi) <= bytes) { lo = hi; hi <<= 1; }
@@ -238,11 +188,26 @@ static int binning_capacity_uncached(size_t bytes, int T, int F, bool legacy) {
   }
   return lo;
 }
+static BinShape bin_shape(const MgsRasterArgs* a, int T, int F) {
+  BinShape s = {-1, 0};
+  if (a->binning_capacity > 0) {
+    if (binning_bytes_T(a->binning_capacity, a->chunk_pool, T, F) > a->binning_bytes) return s;
+    s.cap = a->binning_capacity;
+    s.pool = a->chunk_pool > 0 ? (uint32_t)a->chunk_pool : chunk_pool_max((size_t)s.cap, T);
+    return s;
+  }
+  struct Memo { size_t bytes; int T, F, cap; };
+  static thread_local Memo memo = {0, -1, -1, -1};
+  if (!(memo.bytes == a->binning_bytes && memo.T == T && memo.F == F))
+    memo = {a->binning_bytes, T, F, binning_capacity_uncached(a->binning_bytes, T, F)};
+  s.cap = memo.cap;
+  s.pool = s.cap >= 0 ? chunk_pool_max((size_t)(s.cap > 0 ? s.cap : 1), T) : 0u;
+  return s;
+}
 
-
-// Everything of the forward before the instance count is known: zero tables, preprocess (+ legacy scan).
-static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_t stream, GeomView& g, ImgView& im,
-                              bool& segsort) {
+// Everything of the forward before the instance count is known: zero tables, preprocess (+ rocPRIM scan).
+static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t* radii, hipStream_t stream, GeomView& g,
+                              ImgView& im, bool& segsort) {
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
   if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img ||
       a->img_bytes < mgs_img_bytes(a->W, a->H)) {
@@ -261,12 +226,11 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
   p.focal_y = a->H / (2.0f * a->tanfovy);  // rasterizer_impl.cu:225-226
   p.focal_x = a->W / (2.0f * a->tanfovx);
   p.scale_modifier = a->scale_modifier;
-  p.prefiltered = a->prefiltered; p.tight_bins = options().tight_bins;
+  p.prefiltered = a->prefiltered; p.tight_bins = o.tight_bins;
   p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-  segsort = segsort_binning(p.tiles_x * p.tiles_y);
-  bin_buckets(p.tiles_x * p.tiles_y, &p.NB, &p.bshift);
+  segsort = segsort_binning(o, p.tiles_x * p.tiles_y);
   MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
@@ -291,24 +255,28 @@ static int enqueue_preprocess(const MgsRasterArgs* a, int32_t* radii, hipStream_
 // Blocking read-back of {instance count, flags} (the reference's cudaMemcpy, rasterizer_impl.cu:284).
 static int read_count_blocking(const GeomView& g, int P, bool segsort, hipStream_t stream, uint32_t* R, uint32_t* fl) {
   uint32_t host[2] = {0, 0};
-  MGS_HIP(hipMemcpyAsync(&host[0], segsort ? g.flags + 1 : g.point_offsets + (P - 1), sizeof(uint32_t),
+  MGS_HIP(hipMemcpyAsync(&host[0], segsort ? g.flags + FLAG_NUM_RENDERED : g.point_offsets + (P - 1), sizeof(uint32_t),
                          hipMemcpyDeviceToHost, stream), "num_rendered read-back");
-  MGS_HIP(hipMemcpyAsync(&host[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "flag read-back");
+  MGS_HIP(hipMemcpyAsync(&host[1], g.flags + FLAG_PREFILTERED, sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
+          "flag read-back");
   MGS_HIP(hipStreamSynchronize(stream), "stream sync");
   *R = host[0]; *fl = host[1];
   return MGS_OK;
 }
 
-// Wait for {flags, R} on the pinned status word (written by the binning kernel right after the preprocess).
-static int wait_status(uint64_t* host_status, hipStream_t stream, uint32_t* R, uint32_t* fl) {
+// status word layout: tag (16) | flags (16) | count (32)
+static inline bool status_arrived(uint64_t w, uint32_t tag) { return w != kStatusPending && (uint32_t)(w >> 48) == (tag & 0xffffu); }
+
+// Wait for word 0 = {tag, flags, R} on the pinned status block (written by the binning kernel right after the preprocess).
+static int wait_status(uint64_t* host_status, uint32_t tag, hipStream_t stream, uint32_t* R, uint32_t* fl) {
   volatile uint64_t* hs = host_status;
   uint64_t st = *hs;
-  for (uint64_t spins = 0; st == kStatusPending; spins++) {
+  for (uint64_t spins = 0; !status_arrived(st, tag); spins++) {
     if ((spins & 0x3ff) == 0x3ff) {  // every ~1k polls: has the stream died or finished without reporting?
       hipError_t q = hipStreamQuery(stream);
       if (q != hipErrorNotReady) {
         st = *hs;
-        if (st != kStatusPending) break;
+        if (status_arrived(st, tag)) break;
         set_error("forward finished without reporting the instance count: %s", hipGetErrorString(q));
         return MGS_ERR_HIP;
       }
@@ -316,7 +284,7 @@ static int wait_status(uint64_t* host_status, hipStream_t stream, uint32_t* R, u
     __builtin_ia32_pause();
     st = *hs;
   }
-  *R = (uint32_t)st; *fl = (uint32_t)(st >> 32);
+  *R = (uint32_t)st; *fl = (uint32_t)(st >> 32) & 0xffffu;
   return MGS_OK;
 }
 
@@ -328,61 +296,55 @@ static int check_prefiltered(uint32_t fl) {
   return MGS_OK;
 }
 
-// Binning + render.  R: instance count if the host knows it (legacy binning needs it), else -1.
-// cap: capacity of the binning workspace; host_status: see mgs_rasterize_forward.
-static int enqueue_render(const MgsRasterArgs* a, int R, const int32_t* radii, float* out_color, float* out_feature,
-                          uint64_t* host_status, hipStream_t stream) {
+static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const GeomView& g) {
+  RenderArgs r;
+  const int F = a->include_feature ? a->F : 0;
+  r.W = a->W; r.H = a->H; r.tiles_x = (a->W + TILE - 1) / TILE; r.tiles_y = (a->H + TILE - 1) / TILE;
+  r.F = F; r.include_feature = F > 0;
+  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg;
+  r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
+  r.bg = a->background;
+  r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
+  r.feats = a->language_feature;
+  r.rec = g.rec;
+  return r;
+}
+
+// Binning + render.  R: instance count if the host knows it (the rocPRIM binning needs it), else -1.
+// status: where the device reports (see StatusSink), host == nullptr: nowhere.
+static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const int32_t* radii, float* out_color,
+                          float* out_feature, StatusSink status, hipStream_t stream) {
   const int F = a->include_feature ? a->F : 0;
   const int T = num_tiles(a->W, a->H);
-  const bool segsort = segsort_binning(T);
+  const bool segsort = segsort_binning(o, T);
   GeomView g = carve_geom(a->geom, a->P, a->M, T, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
-  const int cap = binning_capacity(a->binning_bytes, T, F, !segsort);
-  if (!a->binning || cap < 0 || (R >= 0 && R > cap)) {
-    set_error("binning workspace too small: %zu bytes hold %d instances, need %d", a->binning_bytes, cap, R);
+  const BinShape bs = bin_shape(a, T, F);
+  if (!a->binning || bs.cap < 0 || (R >= 0 && R > bs.cap)) {
+    set_error("binning workspace too small: %zu bytes hold %d instances, need %d", a->binning_bytes, bs.cap, R);
     return MGS_ERR_WORKSPACE;
   }
   ChunkView cv;
-  const int CH = carve_chunk();
-  BinView b = carve_binning(a->binning, cap, T, F, CH, !segsort, &cv, nullptr);
+  BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
     StageTimer t(ST_SORT, stream);
-    int NB, bshift;
-    bin_buckets(T, &NB, &bshift);
-    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, cap, NB, bshift, tiles_x, tiles_y, options().seg, !dense_render(),
-                                 host_status, stream),
+    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
               "segment-sort binning", a->debug, stream);
   } else {
     { StageTimer t(ST_DUPLICATE, stream);
-      MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, options().tight_bins, stream),
+      MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, o.tight_bins, stream),
                 "duplicate_with_keys", a->debug, stream); }
     { StageTimer t(ST_SORT, stream);
       MGS_STAGE(launch_sort(b, R, tiles_x, tiles_y, stream), "radix sort", a->debug, stream); }
     { StageTimer t(ST_RANGES, stream);
       MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
   }
-  RenderArgs r;
-  r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
-  r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
-  r.bg = a->background;
-  r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
-  r.feats = a->language_feature;
-  r.rec = g.rec;
+  const RenderArgs r = render_args(a, o, g);
   { StageTimer t(ST_RENDER_FWD, stream);
-    if (dense_render())
-      MGS_STAGE(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, stream), "render forward (dense chunks)",
-                a->debug, stream);
-    else if (CH > 0 && options().render_mode == 2)
-      MGS_STAGE(launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (coop)",
-                a->debug, stream);
-    else if (CH > 0)
-      MGS_STAGE(launch_render_fwd_chunked(r, b, im, cv, out_color, out_feature, stream), "render forward (chunked)",
-                a->debug, stream);
-    else
-      MGS_STAGE(launch_render_fwd(r, b, im, out_color, out_feature, stream), "render forward", a->debug, stream); }
+    MGS_STAGE(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, status, stream), "render forward", a->debug,
+              stream); }
   return MGS_OK;
 }
 
@@ -409,8 +371,9 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   if (!num_rendered) { set_error("num_rendered is NULL"); return MGS_ERR_INVALID_ARG; }
   *num_rendered = 0;
   if (a->P == 0) return MGS_OK;  // rasterize_points.cu:92
+  const Options o = options_of(a);
   GeomView g; ImgView im; bool segsort;
-  rc = enqueue_preprocess(a, radii, stream, g, im, segsort);
+  rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
   rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
@@ -435,7 +398,7 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
     set_error("geom/img workspace too small");
     return MGS_ERR_WORKSPACE;
   }
-  return enqueue_render(a, R, radii, out_color, out_feature, nullptr, stream);
+  return enqueue_render(a, options_of(a), R, radii, out_color, out_feature, StatusSink{nullptr, 0}, stream);
 }
 
 int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_color, float* out_feature,
@@ -447,36 +410,74 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   *num_rendered = 0;
   bool done;
   rc = check_render_args(a, out_color, out_feature, stream, &done);
-  if (rc || done) return rc;
+  if (rc || done) {
+    if (!rc && host_status) {  // P == 0: nothing will report; leave a completed status behind
+      const uint64_t w = (uint64_t)(a->status_tag & 0xffffu) << 48;
+      host_status[0] = w; host_status[1] = w;
+    }
+    return rc;
+  }
+  const Options o = options_of(a);
   GeomView g; ImgView im; bool segsort;
   const int F = a->include_feature ? a->F : 0;
-  const int cap = binning_capacity(a->binning_bytes, num_tiles(a->W, a->H), F, !segsort_binning(num_tiles(a->W, a->H)));
-  if (!a->binning || cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
-  rc = enqueue_preprocess(a, radii, stream, g, im, segsort);
+  const BinShape bs = bin_shape(a, num_tiles(a->W, a->H), F);
+  if (!a->binning || bs.cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
   if (!segsort || !host_status || a->debug) {
     // no device->host status channel: read back (blocking) like the two-call path
+    if (a->async_forward) { set_error("async_forward needs host_status, the segment-sort binning and debug == 0"); return MGS_ERR_INVALID_ARG; }
     rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
     if (rc) return rc;
     rc = check_prefiltered(fl);
     if (rc) return rc;
     *num_rendered = (int32_t)R;
-    if ((int)R > cap) return MGS_NEED_CAPACITY;
-    return enqueue_render(a, (int)R, radii, out_color, out_feature, nullptr, stream);
+    if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
+    // word 1 (chunk-pool report) still comes from the render kernel when there is a status block
+    if (host_status) { volatile uint64_t* hs = host_status; hs[0] = kStatusPending; hs[1] = kStatusPending; }
+    return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, stream);
   }
-  // sync-free: everything is enqueued; the binning kernel stores {flags, R} to the mapped host word as soon
-  // as the preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
+  // sync-free: everything is enqueued; the binning kernel stores {tag, flags, R} to the mapped host word as soon as the
+  // preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
   volatile uint64_t* hs = host_status;
-  *hs = kStatusPending;
-  rc = enqueue_render(a, -1, radii, out_color, out_feature, host_status, stream);
+  hs[0] = kStatusPending; hs[1] = kStatusPending;
+  rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, stream);
   if (rc) return rc;
-  rc = wait_status(host_status, stream, &R, &fl);
+  if (a->async_forward) { *num_rendered = -1; return MGS_OK; }  // the caller reads mgs_forward_result later
+  rc = wait_status(host_status, a->status_tag, stream, &R, &fl);
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
   *num_rendered = (int32_t)R;
-  return (int)R > cap ? MGS_NEED_CAPACITY : MGS_OK;
+  return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
+}
+
+static int forward_result_T(const MgsRasterArgs* a, int T, const uint64_t* host_status, int32_t* num_rendered,
+                            int32_t* chunks_used) {
+  if (num_rendered) *num_rendered = -1;
+  if (chunks_used) *chunks_used = -1;
+  if (!a || !host_status) { set_error("forward_result: NULL argument"); return MGS_ERR_INVALID_ARG; }
+  const volatile uint64_t* hs = host_status;
+  const uint64_t w0 = hs[0], w1 = hs[1];
+  const bool a0 = status_arrived(w0, a->status_tag), a1 = status_arrived(w1, a->status_tag);
+  if (a0 && num_rendered) *num_rendered = (int32_t)(uint32_t)w0;
+  if (a1 && chunks_used) *chunks_used = (int32_t)(uint32_t)w1;
+  if (a0) {
+    const int rc = check_prefiltered((uint32_t)(w0 >> 32) & 0xffffu);
+    if (rc) return rc;
+    if (a->P > 0) {
+      const BinShape bs = bin_shape(a, T, a->include_feature ? a->F : 0);
+      if ((int64_t)(uint32_t)w0 > (int64_t)bs.cap) return MGS_NEED_CAPACITY;  // nothing was binned: word 1 reports 0 chunks
+    }
+  }
+  if (!a0 || !a1) return MGS_PENDING;
+  if ((uint32_t)(w1 >> 32) & 1u) return MGS_NEED_CAPACITY;  // the chunk pool overflowed
+  return MGS_OK;
+}
+int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used) {
+  if (!a) { set_error("forward_result: NULL argument"); return MGS_ERR_INVALID_ARG; }
+  return forward_result_T(a, num_tiles(a->W, a->H), host_status, num_rendered, chunks_used);
 }
 
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* radii, const float* dL_dout_color,
@@ -500,14 +501,14 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     set_error("backward: workspace too small");
     return MGS_ERR_WORKSPACE;
   }
-  const bool segsort = segsort_binning(num_tiles(a->W, a->H));
-  const int cap = binning_capacity(a->binning_bytes, num_tiles(a->W, a->H), F, !segsort);
-  if (cap < 0 || R > cap) { set_error("backward: binning workspace holds %d instances, need %d", cap, R); return MGS_ERR_WORKSPACE; }
-  GeomView g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), nullptr);
+  const Options o = options_of(a);
+  const int T = num_tiles(a->W, a->H);
+  const BinShape bs = bin_shape(a, T, F);
+  if (bs.cap < 0 || R > bs.cap) { set_error("backward: binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
+  GeomView g = carve_geom(a->geom, a->P, a->M, T, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
-  const int CH = carve_chunk();
-  BinView b = carve_binning(a->binning, cap, num_tiles(a->W, a->H), F, CH, !segsort, &cv, nullptr);
+  BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, a->P, a->M, F, nullptr);
   const size_t P = (size_t)a->P;
   // accumulators the render backward adds into
@@ -530,31 +531,11 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
       MGS_HIP(hipMemsetAsync(dcol, 0, 3 * P * sizeof(float), stream), "memset dL_dcolors");
       if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
     } }
-  const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
-  if (R > 0) {
-    RenderArgs r;
-    r.W = a->W; r.H = a->H; r.tiles_x = tiles_x; r.tiles_y = tiles_y; r.F = F; r.include_feature = F > 0;
-    r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = options().dbg;
-  r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
-    r.bg = a->background;
-    r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
-    r.feats = a->language_feature;
-    r.rec = g.rec;
-  r.rec = g.rec;
+  if (R != 0) {  // R < 0: count unknown to the host (asynchronous forward) -- empty ranges make the kernel a no-op
+    const RenderArgs r = render_args(a, o, g);
     StageTimer t(ST_RENDER_BWD, stream);
-    if ((CH == 64 || dense_render()) && options().render_mode == 2 && options().bwd_mode == 1)
-      MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
-                                     dense_render(), stream),
-                "render backward (gaussian-major)", a->debug, stream);
-    else if (CH > 0 && options().render_mode == 2)
-      MGS_STAGE(launch_render_bwd_coop(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
-                                       stream), "render backward (coop)", a->debug, stream);
-    else if (CH > 0)
-      MGS_STAGE(launch_render_bwd_chunked(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature,
-                                          stream), "render backward (chunked)", a->debug, stream);
-    else
-      MGS_STAGE(launch_render_bwd(r, b, im, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
-                "render backward", a->debug, stream);
+    MGS_STAGE(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dcol, dL_dfeature, stream),
+              "render backward", a->debug, stream);
   }
   BwdPreArgs p;
   p.V = 1; p.cov3D_per_view = 0; p.use_cam = 0;
@@ -597,11 +578,10 @@ static int check_views(const MgsRasterArgs* a, int V, const MgsView* views, MgsR
   if (rc) return rc;
   for (int v = 0; v < V; v++)
     if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].campos) { set_error("view %d: NULL matrix", v); return MGS_ERR_INVALID_ARG; }
-  const Options& o = options();
   const Atlas at = atlas_of(a->W, a->H, V);
-  if (o.render_mode != 2 || chunk_size() != 64 || (o.fwd_mode != 1 && o.fwd_mode != 2) || o.bwd_mode != 1 || !segsort_binning(at.T) || a->debug) {
-    set_error("multi-view batches need the default kernels (render_mode 2, chunk 64, fwd_mode 1 or 2, bwd_mode 1, bin_mode 1, "
-              "debug 0) and V * tiles <= %d (got %d)", LDS_TILES, at.T);
+  if (!segsort_binning(options_of(a), at.T) || a->debug) {
+    set_error("multi-view batches need the segment-sort binning (opt.bin_mode 1), debug 0 and V * tiles <= %d (got %d)",
+              LDS_TILES, at.T);
     return MGS_ERR_INVALID_ARG;
   }
   return MGS_OK;
@@ -614,11 +594,11 @@ static void fill_cams(ViewCam* cam, const MgsRasterArgs* a, int V, const MgsView
     cam[v].viewmatrix = views[v].viewmatrix; cam[v].projmatrix = views[v].projmatrix; cam[v].campos = views[v].campos;
   }
 }
-static RenderArgs views_render_args(const MgsRasterArgs* a, const Atlas& at, const GeomView& g) {
+static RenderArgs views_render_args(const MgsRasterArgs* a, const Options& o, const Atlas& at, const GeomView& g) {
   RenderArgs r;
   const int F = a->include_feature ? a->F : 0;
   r.W = a->W; r.H = at.H; r.tiles_x = at.tiles_x; r.tiles_y = at.tiles_yv * at.V; r.F = F; r.include_feature = F > 0;
-  r.fast_exp = options().fast_exp; r.bwd_reduce = options().bwd_reduce; r.exact_cull = options().exact_cull; r.dbg = 0;
+  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = 0;
   r.V = at.V; r.Pg = a->P; r.Hv = a->H; r.Hp = at.Hp;
   r.colors_per_view = a->colors_precomp ? 0 : 1;
   r.bg = a->background;
@@ -635,8 +615,13 @@ size_t mgs_views_geom_bytes(int P, int M, int W, int H, int V) {
 }
 size_t mgs_views_img_bytes(int W, int H, int V) { const Atlas at = atlas_of(W, H, V > 0 ? V : 1); return mgs_img_bytes(W, at.H); }
 size_t mgs_views_binning_bytes(int R, int W, int H, int F, int V) {
-  const Atlas at = atlas_of(W, H, V > 0 ? V : 1);
-  return mgs_binning_bytes(R, W, at.H, F);
+  return binning_bytes_T(R, 0, atlas_of(W, H, V > 0 ? V : 1).T, F);
+}
+size_t mgs_views_binning_bytes2(int R, int chunk_pool, int W, int H, int F, int V) {
+  return binning_bytes_T(R, chunk_pool, atlas_of(W, H, V > 0 ? V : 1).T, F);
+}
+int mgs_views_chunk_pool_max(int R, int W, int H, int V) {
+  return (int)chunk_pool_max(R > 0 ? (size_t)R : 1, atlas_of(W, H, V > 0 ? V : 1).T);
 }
 size_t mgs_views_backward_scratch_bytes(int P, int M, int F, int V) { return mgs_backward_scratch_bytes(P * (V > 0 ? V : 1), M, F); }
 
@@ -654,34 +639,36 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   if (a->P == 0) {
     MGS_HIP(hipMemsetAsync(out_color, 0, (size_t)V * 3 * N * sizeof(float), stream), "memset out_color");
     if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, (size_t)V * F * N * sizeof(float), stream), "memset out_feature");
+    const uint64_t w = (uint64_t)(a->status_tag & 0xffffu) << 48;
+    host_status[0] = w; host_status[1] = w;
     return MGS_OK;
   }
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
+  const Options o = options_of(a);
   const Atlas at = atlas_of(a->W, a->H, V);
   if (!a->geom || a->geom_bytes < mgs_views_geom_bytes(a->P, a->M, a->W, a->H, V) || !a->img ||
       a->img_bytes < mgs_views_img_bytes(a->W, a->H, V) || !a->binning) {
     set_error("views: geom/img/binning workspace missing or too small");
     return MGS_ERR_WORKSPACE;
   }
-  const int cap = binning_capacity(a->binning_bytes, at.T, F, false);
-  if (cap < 0) { set_error("binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  const BinShape bs = bin_shape(a, at.T, F);
+  if (bs.cap < 0) { set_error("binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
   GeomView g = carve_geom(a->geom, a->P * V, a->M, at.T, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   g.flags = im.flags;
   ChunkView cv;
-  BinView b = carve_binning(a->binning, cap, at.T, F, carve_chunk(), false, &cv, nullptr);
+  BinView b = carve_binning(a->binning, bs.cap, at.T, F, bs.pool, &cv, nullptr);
   FwdPreArgs p;
   p.V = V; p.Pg = a->P; p.Hp = at.Hp; p.use_cam = 1;
   p.P = a->P * V; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
   p.tiles_x = at.tiles_x; p.tiles_y = at.tiles_yv;
   p.tanfovx = p.tanfovy = p.focal_x = p.focal_y = 0.f;
   p.scale_modifier = a->scale_modifier;
-  p.prefiltered = a->prefiltered; p.tight_bins = options().tight_bins;
+  p.prefiltered = a->prefiltered; p.tight_bins = o.tight_bins;
   p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = p.projmatrix = p.campos = nullptr;
   fill_cams(p.cam, a, V, views);
-  bin_buckets(at.T, &p.NB, &p.bshift);
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -696,22 +683,28 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;
-  *hs = kStatusPending;
+  hs[0] = kStatusPending; hs[1] = kStatusPending;
+  const StatusSink status = {host_status, a->status_tag};
   { StageTimer t(ST_SORT, stream);
-    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, cap, p.NB, p.bshift, at.tiles_x, at.tiles_yv * V, options().seg,
-                               !dense_render(), host_status, stream),
+    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
             "segment-sort binning (views)"); }
-  const RenderArgs r = views_render_args(a, at, g);
+  const RenderArgs r = views_render_args(a, o, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);
-    MGS_HIP(dense_render() ? launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, stream)
-                           : launch_render_fwd_coop(r, b, im, cv, out_color, out_feature, stream), "render forward (views)"); }
+    MGS_HIP(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, status, stream), "render forward (views)"); }
+  if (a->async_forward) { *num_rendered = -1; return MGS_OK; }
   uint32_t R = 0, fl = 0;
-  rc = wait_status(host_status, stream, &R, &fl);
+  rc = wait_status(host_status, a->status_tag, stream, &R, &fl);
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
   *num_rendered = (int32_t)R;
-  return (int)R > cap ? MGS_NEED_CAPACITY : MGS_OK;
+  return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
+}
+
+int mgs_forward_result_views(const MgsRasterArgs* a, int32_t V, const uint64_t* host_status, int32_t* num_rendered,
+                             int32_t* chunks_used) {
+  if (!a || V < 1) { set_error("forward_result_views: bad argument"); return MGS_ERR_INVALID_ARG; }
+  return forward_result_T(a, atlas_of(a->W, a->H, V).T, host_status, num_rendered, chunks_used);
 }
 
 int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t R, const int32_t* radii,
@@ -730,6 +723,7 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
     set_error("backward (views): a required pointer is NULL");
     return MGS_ERR_INVALID_ARG;
   }
+  const Options o = options_of(a);
   const Atlas at = atlas_of(a->W, a->H, V);
   if (!scratch || scratch_bytes < mgs_views_backward_scratch_bytes(a->P, a->M, F, V) || !a->geom ||
       a->geom_bytes < mgs_views_geom_bytes(a->P, a->M, a->W, a->H, V) || !a->img ||
@@ -737,13 +731,13 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
     set_error("backward (views): workspace too small");
     return MGS_ERR_WORKSPACE;
   }
-  const int cap = binning_capacity(a->binning_bytes, at.T, F, false);
-  if (cap < 0 || R > cap) { set_error("backward (views): binning workspace holds %d instances, need %d", cap, R); return MGS_ERR_WORKSPACE; }
+  const BinShape bs = bin_shape(a, at.T, F);
+  if (bs.cap < 0 || R > bs.cap) { set_error("backward (views): binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
   const size_t PV = (size_t)a->P * V, P = (size_t)a->P;
   GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   ChunkView cv;
-  BinView b = carve_binning(a->binning, cap, at.T, F, carve_chunk(), false, &cv, nullptr);
+  BinView b = carve_binning(a->binning, bs.cap, at.T, F, bs.pool, &cv, nullptr);
   BwdScratch sc = carve_bwd(scratch, (int)PV, a->M, F, nullptr);
   const size_t ncol = a->colors_precomp ? P : PV;  // dL_dcolors rows: per Gaussian (precomputed colours) or per (view, Gaussian)
   if (!a->accum_prezeroed) {
@@ -752,11 +746,10 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
     MGS_HIP(hipMemsetAsync(dL_dcolors, 0, 3 * ncol * sizeof(float), stream), "memset dL_dcolors");
     if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
   }
-  if (R > 0) {
-    const RenderArgs r = views_render_args(a, at, g);
+  if (R != 0) {
+    const RenderArgs r = views_render_args(a, o, at, g);
     StageTimer t(ST_RENDER_BWD, stream);
-    MGS_HIP(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dL_dcolors, dL_dfeature,
-                                 dense_render(), stream),
+    MGS_HIP(launch_render_bwd_gm(r, b, im, cv, dL_dout_color, dL_dout_feature, sc.acc8, dL_dcolors, dL_dfeature, stream),
             "render backward (views)");
   }
   BwdPreArgs p;
@@ -824,6 +817,12 @@ int mgs_selftest(mgs_stream_t stream_) {
   hipFree(d);
   MGS_HIP(e, "selftest");
   if (h != 0) { set_error("wave64 primitive self-test failed, mask 0x%x", h); return h; }
+  return MGS_OK;
+}
+
+int mgs_calibration_kernel(int iters, float* sink, mgs_stream_t stream_) {
+  if (iters < 1 || !sink) { set_error("calibration: iters >= 1 and a sink of 256 * 1024 floats"); return MGS_ERR_INVALID_ARG; }
+  MGS_HIP(launch_calibration(iters, sink, (hipStream_t)stream_), "calibration kernel");
   return MGS_OK;
 }
 

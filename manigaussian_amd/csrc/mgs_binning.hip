@@ -1,5 +1,4 @@
-// mgs_binning.hip -- tile binning (K3-K6): from per-Gaussian tile rects to per-tile, depth-ordered instance
-// lists + the packed sorted instance records the render kernels stream.
+// mgs_binning.hip -- tile binning (K3-K6): from per-Gaussian tile rects to per-tile, depth-ordered instance lists.
 //
 // Two implementations of the same result contract (per tile: instances ordered by view-depth bits, ties by
 // Gaussian index -- what the reference's stable radix sort of (tile<<32 | depth) keys yields,
@@ -9,15 +8,12 @@
 //                         -> rank merge across a tile's segments + emission.  3 launches, no library calls.
 //                         Keys (depth bits, id) are unique, so the order is deterministic and equals the
 //                         stable sort's order.
-//   bin_mode 0 (legacy)   rocPRIM scan + duplicate + rocPRIM SortPairs + ranges/gather: 20+ launches at R~300k
-//                         (rocPRIM picks a merge sort there).  Kept for A/B and for images with more than
-//                         LDS_TILES tiles.
+//   bin_mode 0 (rocPRIM)  scan + duplicate + rocPRIM SortPairs + ranges: 20+ launches at R~300k (rocPRIM picks a merge
+//                         sort there).  The path for images with more than LDS_TILES tiles, and an A/B reference.
 //
 // Follows RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320 for WHAT is produced (64-bit keys
 // tile<<32 | depth bits, stable order, per-tile [start,end) ranges).  The scan and the radix sort come
-// from rocPRIM through hipCUB exactly as the reference takes them from CUB.  New here: K6 also
-// gathers the sorted per-instance record {xy, conic, opacity, cull extents} so that the render kernels
-// stream it linearly (coalesced 32 B/lane) instead of chasing point_list -> means2D/conic_opacity.
+// from rocPRIM through hipCUB exactly as the reference takes them from CUB.
 #include <hipcub/hipcub.hpp>
 
 #include "mgs_common.h"
@@ -91,11 +87,8 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const f
     }
 }
 
-// ranges (rasterizer_impl.cu:116-138) + gather of the packed sorted instance records.
-__global__ void __launch_bounds__(256) ranges_gather_kernel(int L, const uint64_t* __restrict__ keys,
-                                                            const uint32_t* __restrict__ point_list,
-                                                            const float4* __restrict__ rec,
-                                                            uint2* __restrict__ ranges, float4* __restrict__ inst) {
+// ranges (rasterizer_impl.cu:116-138)
+__global__ void __launch_bounds__(256) ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L) return;
   const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
@@ -109,9 +102,6 @@ __global__ void __launch_bounds__(256) ranges_gather_kernel(int L, const uint64_
     }
   }
   if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
-  const uint32_t id = point_list[idx];
-  inst[2 * (size_t)idx] = rec[2 * (size_t)id];
-  inst[2 * (size_t)idx + 1] = rec[2 * (size_t)id + 1];
 }
 
 // rasterizer_impl.cu:35-50
@@ -146,8 +136,8 @@ hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStr
 
 hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im, int R, hipStream_t s) {
   if (R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ranges_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, b.point_list, g.rec,
-                     im.ranges, b.inst);
+  (void)g;
+  hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, im.ranges);
   return hipGetLastError();
 }
 
@@ -203,11 +193,11 @@ __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t
 
 // Workgroups [0, nblk) scatter the keys of PRE_BLOCK Gaussians each (the partition the preprocess used);
 // workgroup nblk publishes ranges and the segment table for the next two kernels.
-// T = tiles, NB = depth buckets per tile: S = T * NB sort slices, slice (tile, bucket) = tile * NB + bucket.
-__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int NB, int bshift, int tiles_x, int nblk,
+// T = tiles = sort slices.
+__global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int tiles_x, int nblk,
                                                                 uint32_t seg,
                                                                 uint32_t capacity, const uint32_t* __restrict__ flags,
-                                                                uint64_t* host_status,
+                                                                uint64_t* host_status, uint32_t status_tag,
                                                                 const uint2* __restrict__ rect,
                                                                 const float* __restrict__ depths,
                                                                 const uint32_t* __restrict__ tile_hist,
@@ -217,7 +207,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
                                                                 uint32_t* __restrict__ seg_base,
                                                                 uint4* __restrict__ seg_desc) {
   extern __shared__ uint32_t lds_u[];
-  const int S = T * NB;
+  const int S = T;
   uint32_t* s_start = lds_u;          // [S] exclusive scan of the histogram
   uint32_t* s_cnt = lds_u + S;        // [S] write cursor of this workgroup inside its reservation
   uint32_t* s_base = lds_u + 2 * S;   // [S] this workgroup's reserved offset inside the slice
@@ -225,9 +215,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   __shared__ uint32_t total;
   const int tid = threadIdx.x;
   const bool tables = (int)blockIdx.x == nblk;
-  const uint32_t R = flags[1];
-  if (tables && tid == 0 && host_status)  // report {flags, R} to the waiting host thread (mapped pinned memory)
-    __hip_atomic_store(host_status, ((uint64_t)flags[0] << 32) | R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint32_t R = flags[FLAG_NUM_RENDERED];
+  if (tables && tid == 0 && host_status)  // report {tag, flags, R} to the host (mapped pinned memory)
+    __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)(flags[FLAG_PREFILTERED] & 0xffffu) << 32) | R,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (R > capacity) {  // the workspace cannot hold the lists: publish "nothing binned", the caller retries
     if (tables) {
       for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(0u, 0u);
@@ -245,10 +236,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   __syncthreads();
   block_exclusive_scan(s_start, S, tmp, &total);
   if (tables) {
-    for (int t = tid; t < T; t += blockDim.x) {  // a tile's list = its slices, one after the other
-      const int last = t * NB + NB - 1;
-      ranges[t] = make_uint2(s_start[t * NB], s_start[last] + tile_hist[last]);
-    }
+    for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(s_start[t], s_start[t] + tile_hist[t]);
     for (int t = tid; t < S; t += blockDim.x) s_base[t] = div_up_u(tile_hist[t], seg);
     __syncthreads();
     block_exclusive_scan(s_base, S, tmp, &total);
@@ -274,10 +262,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   if (x1 <= x0 || y1 <= y0) return;
   const float depth = depths[idx];
   const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
-  const int bk = (int)depth_bucket(depth, NB, bshift);
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) {
-      const int t = (y * tiles_x + x) * NB + bk;
+      const int t = y * tiles_x + x;
       const uint32_t slot = s_start[t] + s_base[t] + atomicAdd(&s_cnt[t], 1u);
       keys_unsorted[slot] = key;
     }
@@ -345,7 +332,7 @@ __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* _
       k1 = up ? hi : lo;
     }
   }
-  if (point_list && cnt == d.w) {  // the slice is this one segment: sorted ids go straight out, the merge kernel skips it
+  if (cnt == d.w) {  // the slice is this one segment: sorted ids go straight out, the merge kernel skips it
     if (e0 < cnt) point_list[base + e0] = (uint32_t)k0;
     if (e0 + 1u < cnt) point_list[base + e0 + 1u] = (uint32_t)k1;
     return;
@@ -368,19 +355,14 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t* a, uint32_t 
 }
 
 // K6': final position of a key = its index + its lower-bound rank in the tile's other segments (keys are unique),
-// staged through LDS in groups of whole segments (<= CAP keys); then emission of the sorted ids and of the packed
-// instance records (gathered early so the gather overlaps the ranking).  One workgroup per segment, two keys per thread.
-// (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores was measured at 45 us
-//  against 19 us for this one at C3: 64 tiles cannot keep 256 CUs busy.)
-// EMIT: also write the packed instance records next to the ids (the entry-chunk render kernels stream them; the dense
-// kernels gather geom.rec by id instead, which spares this kernel its largest read and write).
-template <int SEGN, bool EMIT>
+// staged through LDS in groups of whole segments (<= CAP keys); then emission of the sorted ids.  One workgroup per
+// segment, two keys per thread.  (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores
+// was measured at 45 us against 19 us for this one at C3: 64 tiles cannot keep 256 CUs busy.)
+template <int SEGN>
 __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
                                                                    const uint4* __restrict__ seg_desc,
                                                                    const uint64_t* __restrict__ keys,
-                                                                   const float4* __restrict__ rec,
-                                                                   uint32_t* __restrict__ point_list,
-                                                                   float4* __restrict__ inst) {
+                                                                   uint32_t* __restrict__ point_list) {
   constexpr uint32_t NT = SEGN / 2;
   constexpr uint32_t CAP = 8192;  // keys staged per group (64 KB)
   __shared__ uint64_t sk[CAP];
@@ -388,7 +370,7 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   const uint4 d = seg_desc[blockIdx.x];
   if (blockIdx.x >= *n_seg) return;
   const uint32_t cnt = d.y, start = d.z, L = d.w;
-  if (!EMIT && cnt == L) return;  // single-segment slice: bin_segsort_kernel wrote its ids already
+  if (cnt == L) return;  // single-segment slice: bin_segsort_kernel wrote its ids already
   const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);
   const uint32_t self = (d.x - start) / seglen;
   const uint64_t* __restrict__ tk = keys + start;  // the tile's slice
@@ -400,86 +382,65 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     key[e] = i < cnt ? keys[(size_t)d.x + i] : ~0ull;
     rank[e] = i;
   }
-  // the per-Gaussian record only depends on the id: fetch it now so the gather overlaps the ranking
-  float4 r0[2], r1[2];
-  if constexpr (EMIT) {
+  const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
+  for (uint32_t s0 = 0; s0 < ns; s0 += per_group) {
+    const uint32_t s1 = min(ns, s0 + per_group);
+    if (s1 - s0 == 1 && s0 == self) continue;  // the group holds only this workgroup's own segment
+    const uint32_t k0 = s0 * seglen, nk = min(L, s1 * seglen) - k0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < nk; i0 += NT * 8) {  // 8 loads in flight per thread
+      uint64_t v[8];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const uint32_t id = (tid + e * NT) < cnt ? (uint32_t)key[e] : 0u;
-      r0[e] = rec[2 * (size_t)id];
-      r1[e] = rec[2 * (size_t)id + 1];
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * NT + tid;
+        v[u] = i < nk ? tk[k0 + i] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + u * NT + tid;
+        if (i < nk) sk[i] = v[u];
+      }
     }
-  }
-  if (ns > 1) {
-    const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
-    for (uint32_t s0 = 0; s0 < ns; s0 += per_group) {
-      const uint32_t s1 = min(ns, s0 + per_group);
-      if (s1 - s0 == 1 && s0 == self) continue;  // the group holds only this workgroup's own segment
-      const uint32_t k0 = s0 * seglen, nk = min(L, s1 * seglen) - k0;
-      __syncthreads();
-      for (uint32_t i0 = 0; i0 < nk; i0 += NT * 8) {  // 8 loads in flight per thread
-        uint64_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const uint32_t i = i0 + u * NT + tid;
-          v[u] = i < nk ? tk[k0 + i] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const uint32_t i = i0 + u * NT + tid;
-          if (i < nk) sk[i] = v[u];
-        }
-      }
-      __syncthreads();
-      for (uint32_t s2 = s0; s2 < s1; s2++) {
-        if (s2 == self) continue;
-        const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
-        const uint32_t q0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
-        const uint32_t q1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
-        rank[0] += q0;
-        rank[1] += q1;
-      }
+    __syncthreads();
+    for (uint32_t s2 = s0; s2 < s1; s2++) {
+      if (s2 == self) continue;
+      const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
+      const uint32_t q0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
+      const uint32_t q1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
+      rank[0] += q0;
+      rank[1] += q1;
     }
   }
 #pragma unroll
   for (int e = 0; e < 2; e++) {
     const uint32_t i = tid + e * NT;
-    if (i >= cnt) continue;
-    const size_t out = (size_t)start + rank[e];
-    point_list[out] = (uint32_t)key[e];
-    if constexpr (EMIT) { inst[2 * out] = r0[e]; inst[2 * out + 1] = r1[e]; }
+    if (i < cnt) point_list[(size_t)start + rank[e]] = (uint32_t)key[e];
   }
 }
 
 template <int SEGN>
-static void launch_sort_merge(const GeomView& g, const BinView& b, const ImgView& im, int R, int T, bool emit_inst,
-                              hipStream_t s) {  // T: sort slices
+static void launch_sort_merge(const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
   hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                     b.keys_unsorted, b.keys, emit_inst ? nullptr : b.point_list);
-  if (emit_inst)
-    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, true>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
-                       b.seg_desc, b.keys, g.rec, b.point_list, b.inst);
-  else
-    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, false>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
-                       b.seg_desc, b.keys, g.rec, b.point_list, b.inst);
+                     b.keys_unsorted, b.keys, b.point_list);
+  hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
+                     b.seg_desc, b.keys, b.point_list);
 }
 
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int NB, int bshift, int tiles_x, int tiles_y, int seg, bool emit_inst, uint64_t* host_status, hipStream_t s) {
+                              int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
   const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
   // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
-  const int S = T * NB;  // sort slices
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)S, s, Pg, T, NB,
-                     bshift, tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, host_status, g.rect, g.depths, im.tile_hist, g.blk_base, b.keys_unsorted,
-                     im.ranges, im.seg_base, b.seg_desc);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
+                     tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, g.rect, g.depths,
+                     im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc);
   switch (seg) {
-    case 512: launch_sort_merge<512>(g, b, im, R, S, emit_inst, s); break;
-    case 1024: launch_sort_merge<1024>(g, b, im, R, S, emit_inst, s); break;
-    default: launch_sort_merge<2048>(g, b, im, R, S, emit_inst, s); break;
+    case 512: launch_sort_merge<512>(b, im, R, T, s); break;
+    case 1024: launch_sort_merge<1024>(b, im, R, T, s); break;
+    default: launch_sort_merge<2048>(b, im, R, T, s); break;
   }
   return hipGetLastError();
 }

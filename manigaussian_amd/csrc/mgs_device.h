@@ -17,15 +17,6 @@ __device__ __forceinline__ float dpp_mov(float v) {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Coarse depth bucket of a view-space depth (> 0.2, the near cull): monotone non-decreasing in the depth, so sorting the
-// buckets of a tile one after the other is sorting the tile.  Log-spaced: float bits above those of 0.2f, shifted.
-__device__ __forceinline__ uint32_t depth_bucket(float depth, int NB, int shift) {
-  if (NB <= 1) return 0u;
-  const uint32_t u = __float_as_uint(depth), u0 = 0x3E4CCCCDu;  // bits of 0.2f
-  const uint32_t d = u > u0 ? u - u0 : 0u;
-  return min(d >> shift, (uint32_t)NB - 1u);
-}
-
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ float bcast_lane(float v, int j /*wave-uniform*/) {
@@ -46,61 +37,6 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
   x = __int_as_float(r[0]);
   y = __int_as_float(r[1]);
-}
-
-// One halving step of the transposing butterfly at lane distance D.  Returns a register whose lanes
-// with bit log2(D) == 0 hold x[self] + x[partner] and whose other lanes hold y[self] + y[partner].
-template <int D>
-__device__ __forceinline__ float bfly_halve(float x, float y, int lane) {
-  if constexpr (D == 32) {
-    swap32(x, y);
-    return x + y;
-  } else if constexpr (D == 16) {
-    swap16(x, y);
-    return x + y;
-  } else {
-    const bool hi = (lane & D) != 0;
-    const float keep = hi ? y : x;
-    const float send = hi ? x : y;
-    if constexpr (D == 8) return keep + dpp_mov<DPP_ROW_ROR8>(send);
-    else if constexpr (D == 4) return keep + dpp_mov<DPP_ROW_HALF_MIRROR>(send);
-    else if constexpr (D == 2) return keep + dpp_mov<DPP_QUAD_XOR2>(send);
-    else return keep + dpp_mov<DPP_QUAD_XOR1>(send);
-  }
-}
-
-// All-reduce step at distance D (every lane ends with self + partner).
-template <int D>
-__device__ __forceinline__ float bfly_all(float v) {
-  if constexpr (D == 32) {
-    float y = v;
-    swap32(v, y);
-    return v + y;
-  } else if constexpr (D == 16) {
-    float y = v;
-    swap16(v, y);
-    return v + y;
-  } else if constexpr (D == 8) return v + dpp_mov<DPP_ROW_ROR8>(v);
-  else if constexpr (D == 4) return v + dpp_mov<DPP_ROW_HALF_MIRROR>(v);
-  else if constexpr (D == 2) return v + dpp_mov<DPP_QUAD_XOR2>(v);
-  else return v + dpp_mov<DPP_QUAD_XOR1>(v);
-}
-
-// Transposing butterfly reduction of N (power of two, <= 64) per-lane values over the 64 lanes.
-// On return a[0] in lane l holds the wave-wide sum of value index  (l >> (6 - log2 N)) & (N-1);
-// the lanes whose low (6 - log2 N) bits are zero are the canonical owners.
-template <int N, int D = 32>
-__device__ __forceinline__ void bfly_reduce(float* a, int lane) {
-  if constexpr (D >= 1) {
-    if constexpr (N == 1) {
-      a[0] = bfly_all<D>(a[0]);
-      bfly_reduce<1, D / 2>(a, lane);
-    } else {
-#pragma unroll
-      for (int i = 0; i < N / 2; i++) a[i] = bfly_halve<D>(a[i], a[i + N / 2], lane);
-      bfly_reduce<N / 2, D / 2>(a, lane);
-    }
-  }
 }
 
 // Value of lane (l ^ D) for D in {1,2,4,8,16,32}: DPP within a row, permlane swaps across rows.

@@ -115,7 +115,7 @@ __device__ __forceinline__ void tight_rect(float px, float py, float hx, float h
 template <bool HIST>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
                                                                    int32_t* __restrict__ radii) {
-  extern __shared__ uint32_t s_hist[];  // [tiles * NB] when HIST: instances per sort slice (tile, depth bucket)
+  extern __shared__ uint32_t s_hist[];  // [tiles] when HIST: instances per tile
   __shared__ uint32_t s_total;
   if (HIST && threadIdx.x == 0) s_total = 0;
   // Workgroups never straddle views: view = blockIdx / (workgroups per view), so the camera is wave-uniform.
@@ -133,13 +133,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const bool batch = a.use_cam != 0;
   const float tanfovx = batch ? a.cam[v].tanfovx : a.tanfovx, tanfovy = batch ? a.cam[v].tanfovy : a.tanfovy;
   const float focal_x = batch ? a.cam[v].focal_x : a.focal_x, focal_y = batch ? a.cam[v].focal_y : a.focal_y;
-  const int NB = HIST ? a.NB : 1, S = T * NB;  // sort slices
+  const int S = T;  // sort slices = tiles
   if constexpr (HIST) {
     for (int t = threadIdx.x; t < S; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
   }
   int32_t radius_out = 0;
-  float depth_out = 0.f;  // view-space depth of a binned Gaussian (selects its depth bucket)
   uint32_t touched = 0;
   int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
   if (gi < a.Pg) {
@@ -149,7 +148,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const V3 p = ld3(a.means3D, gi);
   const float view_z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
   if (view_z <= 0.2f) {  // auxiliary.h:154 near cull
-    if (a.prefiltered) atomicOr(&g.flags[0], 1u);
+    if (a.prefiltered) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
   } else {
     const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
     const float p_w = 1.0f / (hw + 0.0000001f);
@@ -239,7 +238,6 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
           g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
         }
         g.depths[idx] = view_z;
-        depth_out = view_z;
         g.rec[2 * (size_t)idx] = make_float4(px, py, conx, cony);  // view-local pixel coordinates
         g.rec[2 * (size_t)idx + 1] = make_float4(conz, opacity, hx, hy);
         radius_out = (int32_t)my_radius;
@@ -254,12 +252,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   g.rect[idx] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
   }  // idx < P
   if constexpr (HIST) {
-    const uint32_t bk = touched ? depth_bucket(depth_out, NB, a.bshift) : 0u;
     for (int y = ry0; y < ry1; y++)
-      for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[(y * a.tiles_x + x) * NB + (int)bk], 1u);
+      for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     if (touched) atomicAdd(&s_total, touched);
     __syncthreads();
-    if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[1], s_total);
+    if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[FLAG_NUM_RENDERED], s_total);
     // reserve this workgroup's slots inside every slice it contributes to; the bin scatter (same
     // PRE_BLOCK partition of the Gaussians) reads the offsets back
     uint32_t* __restrict__ row = a.blk_base + (size_t)blockIdx.x * S;
@@ -274,7 +271,7 @@ hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t
   if (a.P <= 0) return hipSuccess;
   if (a.tile_hist)
     hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK)), dim3(PRE_BLOCK),
-                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V * a.NB, s, a, g, radii);
+                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, a, g, radii);
   else
     hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.Pg + 255) / 256), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();

@@ -1,13 +1,12 @@
-// mgs_render_bwd_gm.hip -- Gaussian-major render backward (K8) for the cooperative chunk-parallel forward, gfx950.
+// mgs_render_bwd_gm.hip -- Gaussian-major render backward (K8) for the chunk-parallel forward (mgs_render_dense.hip), gfx950.
 //
 // Results: the reference's renderCUDA backward (RAST/cuda_rasterizer/backward.cu:399-593): for every blended
 // (pixel, Gaussian) pair  dL/dalpha = (D - accum_rec.dL) * T_before - T_final/(1-alpha) * (bg.dL_rgb)  with
 // D = colour/feature row . dL_dpixel, then the chain to mean2D (NDC units), conic, opacity, colour and feature
 // rows, summed over the pixels.  Which pairs are blended comes from the forward (last_pos, T_end per chunk).
 //
-// Decomposition.  mgs_render_coop.hip's backward keeps lane = pixel and, per Gaussian, reduces 9+F values over
-// the 64 pixel lanes with a butterfly: measured VALU-bound (8000 VALU instr. per wave, half of them reduction).
-// Here the roles flip inside a chunk:
+// Decomposition.  A pixel-major backward (lane = pixel) has to reduce 9+F values per Gaussian over the 64 pixel lanes:
+// measured VALU-bound (8000 VALU instr. per wave, half of them reduction).  Here the roles flip inside a chunk:
 //   lane (n, h) = Gaussian n (0..31) of a group of <= 32 block-reaching entries of the chunk, h = pixel half;
 //   the lane walks its 32 pixels p(u, r, h) = 32u + (r&3) + 8(r>>2) + 4h serially, so every per-Gaussian sum
 //   (mean2D, conic, opacity, colour) is a private register accumulation -- no cross-lane reduction at all;
@@ -38,15 +37,15 @@ struct GmCfg {
 template <bool FAST>
 __device__ __forceinline__ float gm_exp(float x) { return exp_<FAST>(x); }
 
-// Per-wave LDS record of one compacted entry: {index into the tile's sorted instance list, 1-based position in the chunk}
+// Per-wave LDS record of one entry: {instance id, 1-based position in the chunk}
 struct GmRec { float4 g0, g1; uint32_t id, pos; };
 
-// DENSE: the forward was coop_fwd_dense_kernel (mgs_render_dense.hip): a chunk is 64 consecutive SURVIVORS of this block's
-// compacted list `surv` (no culling here, groups are full) and T_mid is the transmittance entering the second group.
-template <int F, bool FAST, bool EXACT, int NW, bool DENSE>
-__global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const float4* __restrict__ inst,
+// A chunk is 64 consecutive SURVIVORS of this block's compacted list `surv` (written by the forward: no culling here,
+// groups are full) and T_mid is the transmittance entering the second group.  Chunk c's record is
+// round_base[round c / NWF] + c % NWF with NWF = the forward's waves (FwdWaves<F>).
+template <int F, bool FAST, int NW>
+__global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ round_base,
                                                           const uint32_t* __restrict__ last_chunk,
                                                           const float* __restrict__ T_end,
                                                           const uint32_t* __restrict__ last_pos,
@@ -60,6 +59,10 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
                                                           const uint32_t* __restrict__ nsurv) {
   using C = GmCfg<F>;
   constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
+  constexpr int CH = CHUNK;
+  constexpr uint32_t NWF = FwdWaves<F>::value;
+  constexpr uint32_t RBH = 32;            // rounds whose first record is staged in LDS
+  __shared__ uint32_t rb_hist[RBH];
   __shared__ float dLT[KCH][64];          // [channel][pixel]: A operand of the D contraction
   __shared__ float dLs[64 * SROW];        // [pixel][feature channel, zero padded]: A operand of the feature contraction
   __shared__ float4 pd[NW][64];           // per wave, per pixel: {T_in, S_after + T_final*bg.dL, last (bits), T_in of group 1}
@@ -81,6 +84,13 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
   const size_t pix = p.pixl;
   const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+  const uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);
+  if (tid < (int)RBH && (uint32_t)tid * NWF < lcmax) rb_hist[tid] = my_rounds[4 * (size_t)tid];
+  __syncthreads();
+  auto slot_of = [&](uint32_t c) -> size_t {
+    const uint32_t rr = c / NWF;
+    return (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (size_t)(c % NWF);
+  };
 
   // ---- pixel-lane prologue: dL of this block into LDS (both layouts), q[c] = dL . partial[c] ----
   const float T_final = any ? final_T[p.pixa] : 0.f;
@@ -114,7 +124,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       for (int ch = NCH; ch < KCH; ch++) dLT[ch][lane] = 0.f;
     }
     for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
-      const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+      const size_t slot = slot_of(c);
       float s = 0.f;
       if (c < lc) {
         const float* pp = partial + slot * NCH * 64 + lane;
@@ -135,25 +145,24 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
   const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
   const int n = lane & 31, h = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
-  uint32_t nsb = 0;                          // DENSE: survivors the forward listed for this block
-  if constexpr (DENSE) nsb = nsurv[(size_t)tile * 4 + sub];
+  const uint32_t nsb = nsurv[(size_t)tile * 4 + sub];  // survivors the forward listed for this block
 
   for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
     // ---- pixel-lane: state of this chunk for my pixel ----
-    const size_t slot = chunk_slot(rng.x, tile, CH, c, sub);
+    const size_t slot = slot_of(c);
     const uint32_t last = (c < lc) ? last_pos[slot * 64 + lane] : 0u;
     const uint32_t kmax = wave_umax(last);
     if (kmax == 0) continue;
     const bool live = last > 0;
     float B = 0.f;
     for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
-      const float v = q[chunk_slot(rng.x, tile, CH, c2, sub) * 64 + lane];
+      const float v = q[slot_of(c2) * 64 + lane];
       B += (live && c2 < lc) ? v : 0.f;
     }
-    const float T_in = (live && c > 0) ? T_end[chunk_slot(rng.x, tile, CH, c - 1, sub) * 64 + lane] : 1.0f;
+    const float T_in = (live && c > 0) ? T_end[slot_of(c - 1) * 64 + lane] : 1.0f;
     // ---- entry-lane: the chunk's entries that reach this 8x8 block, compacted in order ----
     int ns;
-    if constexpr (DENSE) {
+    {
       const uint32_t first = c * (uint32_t)CH;
       const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
       ns = (int)min(nin, kmax);
@@ -167,23 +176,6 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
       pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
       rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = make_uint2(id_e, (uint32_t)lane + 1u);
-      wave_lds_sync();
-    } else {
-      const uint32_t e = rng.x + c * (uint32_t)CH + (uint32_t)lane;
-      const bool valid = e < rng.y && (uint32_t)lane + 1u <= kmax;
-      float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
-      uint32_t id_e = 0;
-      if (valid) { g0 = inst[2 * (size_t)e]; g1 = inst[2 * (size_t)e + 1]; id_e = point_list[e]; }
-      const bool surv_e = valid && cull_ok<EXACT>(g0, g1, p);
-      const unsigned long long smask = ballot(surv_e);
-      ns = __builtin_popcountll(smask);
-      if (ns == 0) continue;
-      wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
-      pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), 1.0f);
-      if (surv_e) {
-        const int rk = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
-        rec0[w][rk] = g0; rec1[w][rk] = g1; recid[w][rk] = make_uint2(id_e, (uint32_t)lane + 1u);
-      }
       wave_lds_sync();
     }
     const int ngroups = (ns + 31) >> 5;
@@ -204,30 +196,6 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
       const uint32_t id = rec.id;                 // instance id (virtual in a multi-view batch): acc8 / per-view colour row
       const uint32_t gidn = gauss_of(r, id);      // the Gaussian: feature row, feature gradient
       const uint32_t cid = r.colors_per_view ? id : gidn;
-
-      if (!DENSE && g == 1) {
-        // group 1 starts from T_in * prod over group 0 of (1 - alpha): a light pass over group 0's entries
-        GmRec r0;  // group 0 is full when a group 1 exists
-        r0.g0 = rec0[w][n]; r0.g1 = rec1[w][n]; r0.pos = recid[w][n].y; r0.id = 0;
-#pragma unroll 1
-        for (int u = 0; u < 2; u++) {
-#pragma unroll 1
-          for (int rr = 0; rr < 16; rr++) {
-            const int pp = 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            const float4 st = pd[w][pp];
-            const float dx = r0.g0.x - (bx0 + (float)((rr & 3) + 4 * h));
-            const float dy = r0.g0.y - (by0 + (float)(4 * u + (rr >> 2)));
-            const float power = -0.5f * (r0.g0.z * dx * dx + r0.g1.x * dy * dy) - r0.g0.w * dx * dy;
-            const float alpha = fminf(0.99f, r0.g1.y * gm_exp<FAST>(power));
-            const bool act = r0.pos <= __float_as_uint(st.z) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const float om = act ? 1.0f - alpha : 1.0f;
-            const float incl = half_excl_scan_mul(om, lane) * om;
-            const float tot = half_last(incl, lane);
-            if (n == 0) pd[w][pp].w = st.x * tot;
-          }
-        }
-        wave_lds_sync();
-      }
 
       float a_mx = 0.f, a_my = 0.f, a_cx = 0.f, a_cy = 0.f, a_cz = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
       f32x16 Cf[NCT > 0 ? NCT : 1];
@@ -360,39 +328,36 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, int CH, c
 
 // ------------------------------------------- dispatch ------------------------------------------------
 template <int F>
-static hipError_t gm_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, const float* dc,
-                       const float* df, float* acc8, float* dcol, float* dfeat, bool dense, hipStream_t s) {
+static hipError_t gm_F(const RenderArgs& r, const ImgView& im, const ChunkView& cv, const float* dc, const float* df,
+                       float* acc8, float* dcol, float* dfeat, hipStream_t s) {
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_GM_(FAST, EXACT, NW, DENSE)                                                                               \
-  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, EXACT, NW, DENSE>), dim3(grid), dim3(NW * 64), 0, s, r, cv.CH, im.ranges, \
-                     b.point_list, b.inst, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, \
-                     acc8, dcol, dfeat, cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
-#define MGS_GM(FAST, EXACT, NW)                                                                                       \
-  do { if (dense) MGS_GM_(FAST, true, NW, true); else MGS_GM_(FAST, EXACT, NW, false); } while (0)
+#define MGS_GM(FAST, NW)                                                                                              \
+  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, NW>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges, cv.round_base,       \
+                     cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, acc8, dcol, dfeat,   \
+                     cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
   // 8 waves per workgroup: 256 registers per lane (no spills); 16 waves: more latency hiding, 128 registers
   bool launched = false;
   if constexpr (F <= 32) {
-    if (options().gm_waves != 8) {
-      if (r.fast_exp) { if (r.exact_cull) MGS_GM(true, true, 16); else MGS_GM(true, false, 16); }
-      else            { if (r.exact_cull) MGS_GM(false, true, 16); else MGS_GM(false, false, 16); }
+    if (r.gm_waves != 8) {
+      if (r.fast_exp) MGS_GM(true, 16); else MGS_GM(false, 16);
       launched = true;
     }
   }
   if (!launched) {
-    if (r.fast_exp) MGS_GM(true, true, 8); else MGS_GM(false, true, 8);
+    if (r.fast_exp) MGS_GM(true, 8); else MGS_GM(false, 8);
   }
 #undef MGS_GM
-#undef MGS_GM_
   return hipGetLastError();
 }
 
 hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
                                 const float* dL_dcolor_px, const float* dL_dfeat_px, float* acc8, float* dL_dcolors,
-                                float* dL_dfeat, bool dense, hipStream_t s) {
+                                float* dL_dfeat, hipStream_t s) {
+  (void)b;
   const int F = r.include_feature ? r.F : 0;
   switch (F) {
-#define X(N) case N: return gm_F<N>(r, b, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, dense, s);
+#define X(N) case N: return gm_F<N>(r, im, cv, dL_dcolor_px, dL_dfeat_px, acc8, dL_dcolors, dL_dfeat, s);
     MGS_FOR_EACH_F(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -5,12 +5,6 @@
 
 namespace mgs {
 
-template <int F>
-struct Row {
-  static constexpr int NCH = F + 3;
-  static constexpr int ROW4 = (NCH + 3) / 4;  // float4 per staged row: [f0..fF-1, r, g, b, pad]
-};
-
 template <bool FAST>
 __device__ __forceinline__ float exp_(float x) {
   if constexpr (FAST) return __expf(x);
@@ -23,37 +17,6 @@ __device__ __forceinline__ void map_block(int b, int& tile, int& sub) {
   tile = (b / 32) * 8 + (b % 8);
   sub = (b / 8) % 4;
 }
-
-template <int F>
-__device__ __forceinline__ void stage_row(float4* stage, int lane, uint32_t id, uint32_t cid,
-                                          const float* __restrict__ colors, const float* __restrict__ feats) {
-  constexpr int ROW4 = Row<F>::ROW4;
-  float tmp[ROW4 * 4];
-#pragma unroll
-  for (int i = 0; i < ROW4 * 4; i++) tmp[i] = 0.f;
-  if constexpr (F > 0) {
-    if (feats) {
-      if constexpr (F % 4 == 0) {
-        const float4* src = reinterpret_cast<const float4*>(feats + (size_t)id * F);
-#pragma unroll
-        for (int i = 0; i < F / 4; i++) {
-          const float4 v = src[i];
-          tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < F; i++) tmp[i] = feats[(size_t)id * F + i];
-      }
-    }
-  }
-  tmp[F] = colors[(size_t)cid * 3];      // id: Gaussian (feature row); cid: colour row (per view when it comes from SH)
-  tmp[F + 1] = colors[(size_t)cid * 3 + 1];
-  tmp[F + 2] = colors[(size_t)cid * 3 + 2];
-#pragma unroll
-  for (int i = 0; i < ROW4; i++)
-    stage[lane * ROW4 + i] = make_float4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
-}
-
 
 // conservative lane-parallel cull of one instance record against a pixel block [bxmin,bxmax]x[bymin,bymax]
 __device__ __forceinline__ bool overlaps_block(const float4& g0, const float4& g1, float bxmin, float bxmax,
@@ -139,11 +102,17 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// storage index of chunk c of a tile whose list starts at x: floor(x/CH) + tile + c  (collision-free and
-// bounded by R/CH + T, so no prefix table is needed)
-__device__ __forceinline__ size_t chunk_slot(uint32_t range_x, int tile, int CH, uint32_t c, int sub) {
-  return ((size_t)(range_x / (uint32_t)CH) + (size_t)tile + c) * 4 + (size_t)sub;
+// Chunk records live in a pool (ChunkView): round r of block (tile, sub) owns the <= NWF consecutive records starting at
+// round_base[round_entry(...)], NWF = waves of the render forward = chunks per round.  A block's rounds number at most
+// len/512 + 1 (len = its tile's list length, a round consumes >= 512 survivors unless it is the last), so the entries
+// range_x/512 + 2*tile + r are collision-free across tiles and bounded by R/512 + 2T.
+constexpr uint32_t ROUND_GRANULE = 512;
+__device__ __forceinline__ size_t round_entry(uint32_t range_x, int tile, int sub, uint32_t r) {
+  return ((size_t)(range_x / ROUND_GRANULE) + 2 * (size_t)tile + r) * 4 + (size_t)sub;
 }
+// waves (= chunks per round) of the render forward for feature width F: 16 waves x 128 registers fill a CU; wide rows
+// (F = 64) need 256 registers
+template <int F> struct FwdWaves { static constexpr int value = F <= 32 ? 16 : 8; };
 
 // Feature widths compiled in.  Other widths are padded up by the host shim (zero channels change nothing).
 #define MGS_FOR_EACH_F(X) X(0) X(3) X(4) X(8) X(16) X(32) X(64)

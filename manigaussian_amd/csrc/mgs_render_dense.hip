@@ -1,24 +1,21 @@
 // mgs_render_dense.hip -- cooperative chunk-parallel render forward over SURVIVOR-DENSE chunks, gfx950.
 //
-// Results: the reference's renderCUDA forward (RAST/cuda_rasterizer/forward.cu:262-398), same per-pixel test order and
-// stop rule; see mgs_render.hip for the semantics and mgs_render_coop.hip for the chunk-parallel decomposition
-// (phase A: per-chunk transmittance products; prefix in chunk order; phase B: blend from the exact T_in).
+// Results: the reference's renderCUDA forward (RAST/cuda_rasterizer/forward.cu:262-398), same per-pixel test order
+// (power > 0 skip, alpha = min(0.99, o e^p), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop WITHOUT blending) and stop rule.
 //
-// What changes against coop_fwd64_kernel: there a chunk is 64 consecutive ENTRIES of the tile's list, of which on average
-// 34 reach a given 8x8 pixel block (measured at BASELINE configs[2]: mean 33.7, i.e. centred on the 32-lane group size of
-// the Gaussian-major backward, which therefore ran a second, almost empty group for half of the chunks: 65 % lane
-// occupancy).  Here the workgroup first compacts the list, in order, to the entries that reach ITS block (block-wide
-// ballot/popcount scan; the survivors' instance ids go to a per-block list in memory that the rounds and later the backward
-// read), and a chunk is 64 consecutive SURVIVORS: every wave blends exactly 64 useful entries per round (perfect balance,
-// half as many per-chunk state records), and the backward gets full groups and no culling of its own.  Records are gathered
-// from geom.rec by id (L2-resident), so the binning does not emit per-instance record copies for these kernels.  T_mid
-// (transmittance after the first 32 survivors of a chunk) is kept so that the backward's second group starts without a
-// recomputation pass.
+// Decomposition: one workgroup of NW waves per 8x8 pixel block, lane = pixel.  The workgroup first compacts its tile's
+// sorted list, in order, to the entries that reach ITS block (block-wide ballot/popcount scan; the survivors' instance ids
+// go to a per-block list in memory that the rounds and later the backward read); a chunk is 64 consecutive SURVIVORS and a
+// round is NW chunks, one per wave: phase A = per-chunk transmittance products, prefix in chunk order through LDS (every
+// consumer sees bit-identical transmittances), phase B = blend from the exact T_in.  Records are gathered from geom.rec by
+// id (L2-resident).  Per chunk the kernel keeps T_end, T_mid (transmittance after the first 32 survivors, where the
+// backward's second group starts), the last blended position and the partial colour sums; the records come from a pool
+// (ChunkView): one atomic per round takes the round's <= NW records.
 #include "mgs_render_common.h"
 
 namespace mgs {
 
-// Phase timeline (diagnostic, mgs_set_option("dbg", 256)): s_memtime stamps per (workgroup, wave, event).
+// Phase timeline (diagnostic, MgsOptions.dbg = 256): s_memtime stamps per (workgroup, wave, event).
 constexpr int TRACE_EVENTS = 24;
 __device__ unsigned long long g_trace[512 * 16 * TRACE_EVENTS];
 #define MGS_TRACE(ev)                                                                                      \
@@ -46,10 +43,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
                       float* __restrict__ T_end, float* __restrict__ T_mid,
                       uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
                       size_t surv_stride, uint32_t* __restrict__ nsurv, float* __restrict__ final_T,
-                      uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat) {
+                      uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat,
+                      uint32_t* __restrict__ round_base, uint32_t pool, uint32_t* __restrict__ flags, int nblocks,
+                      uint64_t* host_status, uint32_t status_tag) {
   static_assert(CHS == 32 || CHS == 64, "a chunk is one or two 32-lane groups of the Gaussian-major backward");
   using f32x16 = __attribute__((ext_vector_type(16))) float;
-  constexpr int CREC = CHS;                  // survivors per chunk record
   constexpr int NCH = F + 3;
   constexpr bool MF = F >= 16;               // feature channels on the matrix cores
   constexpr int NT = MF ? (F + 31) / 32 : 0; // 32-channel tiles
@@ -65,14 +63,19 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   __shared__ float red_Tf[64];
   __shared__ uint32_t red_vis[64];
   __shared__ uint32_t cnt[2][FILLK * NW];    // survivors per (sub-step, wave) of a fill step, double buffered
+  __shared__ uint32_t rbase[2];              // first chunk record of the round (pool index), double buffered over rounds
+  constexpr uint32_t RBH = 16;               // rounds whose first record is also kept in LDS for the final sum
+  __shared__ uint32_t rb_hist[RBH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: tell the compiler (scalar branches)
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
-  if (tile >= r.tiles_x * r.tiles_y) return;
+  if (tile >= r.tiles_x * r.tiles_y) return;  // padding blocks of the grid (not counted in nblocks)
   const PixBlk p = pix_blk(r, tile, sub, lane);
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
+  uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);  // entry of round k: my_rounds[4 * k]
+  bool overflow = false;   // the chunk pool ran out (workgroup-uniform): stop, the host will see the flag
   uint32_t* my_surv = surv + (size_t)sub * surv_stride + rng.x;  // this block's compacted list of instance ids: at most len entries
 
   float Tround = 1.0f;
@@ -140,6 +143,12 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     uint32_t nchunk = exhausted ? (avail + CHS - 1) / CHS : avail / CHS;
     nchunk = min(nchunk, (uint32_t)NW);
     if (nchunk == 0) break;
+    if (tid == 0) {  // this round's chunk records: one returning atomic, consumed after phase A (latency hidden)
+      const uint32_t b0 = atomicAdd(&flags[FLAG_CHUNKS_USED], nchunk);
+      rbase[round & 1] = b0;
+      if (round < RBH) rb_hist[round] = b0;
+      my_rounds[4 * (size_t)round] = b0;  // for the backward
+    }
     const uint32_t c = cbase + (uint32_t)w;
     const bool has = (uint32_t)w < nchunk;
     const uint32_t n_my = has ? min((uint32_t)CHS, avail - (uint32_t)w * CHS) : 0u;  // survivors of my chunk
@@ -211,6 +220,8 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     Tp[round & 1][w][lane] = tp;
     __syncthreads();
     MGS_TRACE(5 + 8 * round);
+    const uint32_t rb = rbase[round & 1];
+    if (rb + nchunk > pool) { overflow = true; break; }  // uniform: every thread reads the same word
     // ---- prefix in chunk order (identical arithmetic in every wave) ----
     float T = Tround, Tnext = Tround;
 #pragma unroll
@@ -307,7 +318,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
         wave_lds_sync();  // the next round's writes come after these reads
       }
       MGS_TRACE(6 + 8 * round);
-      const size_t slot = chunk_slot(rng.x, tile, CREC, c, sub);
+      const size_t slot = (size_t)rb + (size_t)w;
       T_end[slot * 64 + lane] = T;
       if (CHS > 32) T_mid[slot * 64 + lane] = Tm;
       last_pos[slot * 64 + lane] = last;
@@ -341,7 +352,10 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     float v[4][NOWN];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const float* pp = partial + chunk_slot(rng.x, tile, CREC, c0 + u, sub) * NCH * 64 + lane;
+      const uint32_t cc = c0 + u;
+      const uint32_t rr = cc / NW;
+      const size_t slot = cc < vis ? (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (cc % NW) : 0;
+      const float* pp = partial + slot * NCH * 64 + lane;
 #pragma unroll
       for (int k = 0; k < NOWN; k++) {
         const int ch = w + k * NW;
@@ -366,7 +380,18 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   if (w == 0) {
     last_chunk[((size_t)tile * 4 + sub) * 64 + lane] = vis;
     if (p.inside) final_T[p.pixa] = Tf;
-    if (lane == 0) nsurv[(size_t)tile * 4 + sub] = qtail;
+    if (lane == 0) {
+      nsurv[(size_t)tile * 4 + sub] = qtail;
+      // the last workgroup to finish reports {tag, overflow, chunk records used} to the host (mapped pinned memory)
+      if (overflow) atomicOr(&flags[FLAG_PREFILTERED], 0x100u);
+      __threadfence();
+      if (atomicAdd(&flags[FLAG_BLOCKS_DONE], 1u) + 1u == (uint32_t)nblocks && host_status) {
+        const uint32_t used = __hip_atomic_load(&flags[FLAG_CHUNKS_USED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ovf = (__hip_atomic_load(&flags[FLAG_PREFILTERED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) & 1u;
+        __hip_atomic_store(host_status + 1, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)ovf << 32) | used,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
   MGS_TRACE(TRACE_EVENTS - 1);
 }
@@ -374,32 +399,26 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 // ------------------------------------------- dispatch ------------------------------------------------
 template <int F>
 static hipError_t dense_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, float* oc,
-                          float* of, hipStream_t s) {
-  constexpr int NW = F <= 32 ? 16 : 8;  // 16 waves x 128 registers fill a CU; wide rows (F = 64) need 256 registers
+                          float* of, StatusSink st, hipStream_t s) {
+  constexpr int NW = FwdWaves<F>::value;
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_CFD_(FAST, EXACT, CHS)                                                                                    \
-  hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHS>), dim3(grid), dim3(NW * 64), 0, s, r,             \
-                     im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
-                     cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of)
 #define MGS_CFD(FAST, EXACT)                                                                                          \
-  do {                                                                                                                \
-    if (variant == 2) MGS_CFD_(FAST, EXACT, 32);                                                                      \
-    else MGS_CFD_(FAST, EXACT, 64);                                                                                   \
-  } while (0)
-  const int variant = options().dense_variant;  // 1: 64 survivors per chunk (default), 2: 32
+  hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHUNK>), dim3(grid), dim3(NW * 64), 0, s, r,           \
+                     im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
+                     cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of, cv.round_base, cv.pool, im.flags,   \
+                     4 * T, st.host, st.tag)
   if (r.fast_exp) { if (r.exact_cull) MGS_CFD(true, true); else MGS_CFD(true, false); }
   else            { if (r.exact_cull) MGS_CFD(false, true); else MGS_CFD(false, false); }
 #undef MGS_CFD
-#undef MGS_CFD_
   return hipGetLastError();
 }
 
 hipError_t launch_render_fwd_dense(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv,
-                                   float* out_color, float* out_feat, hipStream_t s) {
+                                   float* out_color, float* out_feat, StatusSink st, hipStream_t s) {
   const int F = r.include_feature ? r.F : 0;
   switch (F) {
-#define X(N) case N: return dense_F<N>(r, b, im, cv, out_color, out_feat, s);
+#define X(N) case N: return dense_F<N>(r, b, im, cv, out_color, out_feat, st, s);
     MGS_FOR_EACH_F(X)
 #undef X
     default: return hipErrorInvalidValue;

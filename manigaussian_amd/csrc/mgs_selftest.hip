@@ -1,0 +1,107 @@
+// mgs_selftest.hip -- device self-test of the wave64 cross-lane primitives the kernels rely on (mgs_selftest) and a
+// kernel with a KNOWN instruction mix for validating rocprofv3 counter passes (mgs_calibration_kernel).
+#include "mgs_common.h"
+#include "mgs_device.h"
+
+namespace mgs {
+
+// Checks the cross-lane primitives against their definitions with small integers (exact in fp32).
+__global__ void selftest_kernel(int* result) {
+  const int lane = threadIdx.x;
+  int bad = 0;
+  {  // swap32: lanes 32..63 of x <-> lanes 0..31 of y
+    float x = (float)lane, y = (float)(100 + lane);
+    swap32(x, y);
+    const float ex = lane < 32 ? (float)lane : (float)(100 + lane - 32);
+    const float ey = lane < 32 ? (float)(lane + 32) : (float)(100 + lane);
+    if (x != ex || y != ey) bad |= 1;
+  }
+  if (bcast_lane((float)lane, 37) != 37.f) bad |= 2048;
+  if (bcast_lane_u32((uint32_t)lane * 5u, 63) != 315u) bad |= 4096;
+  if (wave_umax((uint32_t)lane * 3u) != 189u) bad |= 8192;
+  {
+    const uint32_t v = (uint32_t)lane * 2654435761u;
+    if (lane_xor<1>(v, lane) != (uint32_t)(lane ^ 1) * 2654435761u) bad |= 1 << 14;
+    if (lane_xor<2>(v, lane) != (uint32_t)(lane ^ 2) * 2654435761u) bad |= 1 << 15;
+    if (lane_xor<4>(v, lane) != (uint32_t)(lane ^ 4) * 2654435761u) bad |= 1 << 16;
+    if (lane_xor<8>(v, lane) != (uint32_t)(lane ^ 8) * 2654435761u) bad |= 1 << 17;
+    if (lane_xor<16>(v, lane) != (uint32_t)(lane ^ 16) * 2654435761u) bad |= 1 << 18;
+    if (lane_xor<32>(v, lane) != (uint32_t)(lane ^ 32) * 2654435761u) bad |= 1 << 19;
+  }
+  {  // half-wave scans (small integers: exact in float)
+    const int n = lane & 31;
+    const float a = (float)((lane * 5) % 7 + 1);
+    float ea = 0.f;
+    for (int i = 0; i <= n; i++) ea += (float)((((lane & 32) + i) * 5) % 7 + 1);
+    if (half_incl_scan_add(a) != ea) bad |= 1 << 20;
+    const float m = (lane % 3 == 0) ? 2.f : 1.f;
+    float em = 1.f;
+    for (int i = 0; i < n; i++) em *= (((lane & 32) + i) % 3 == 0) ? 2.f : 1.f;
+    if (half_excl_scan_mul(m, lane) != em) bad |= 1 << 21;
+    if (half_last((float)lane, lane) != ((lane & 32) ? 63.f : 31.f)) bad |= 1 << 22;
+  }
+  {  // the fp32 MFMA the render kernels use is exact fp32: C = A (32x2) * B (2x32) with small integers
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    f32x16 c;
+    for (int i = 0; i < 16; i++) c[i] = 0.f;
+    const float a = (float)((lane & 31) + 1 + 100 * (lane >> 5));  // A[i = lane & 31][k = lane >> 5]
+    const float b = (float)(2 * (lane & 31) + 1 + (lane >> 5));    // B[k = lane >> 5][j = lane & 31]
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    for (int i = 0; i < 16; i++) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), col = lane & 31;
+      const float want = (float)(row + 1) * (float)(2 * col + 1) + (float)(row + 101) * (float)(2 * col + 2);
+      if (c[i] != want) bad |= 1 << 23;
+    }
+  }
+  if (bad) atomicOr(result, bad);
+}
+
+hipError_t launch_selftest(int* result_dev, hipStream_t s) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, s, result_dev);
+  return hipGetLastError();
+}
+
+// Known instruction mix per wave and iteration: 64 v_fma_f32, 8 v_mfma_f32_32x32x2_f32, 4 ds_read_b32 (+ loop overhead:
+// one s_add / s_cmp / s_cbranch).  256 workgroups x 4 waves.  scripts/sq_counters.py divides the counters of this
+// kernel by (256 * 4 * iters) and expects 64 / 8 / 4 before it trusts a pass.
+__global__ void __launch_bounds__(256) calibration_kernel(int iters, float* __restrict__ sink) {
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  __shared__ float lds[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) lds[i] = (float)i * 1e-3f;
+  __syncthreads();
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = (float)(tid + i) * 1e-6f;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+  const float m = 0.999f;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(m), "v"(v[(i + 1) & 7]));
+      asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(v[k]), "v"(m));
+    }
+    asm volatile("ds_read_b32 %0, %1" : "=v"(l0) : "v"((tid & 255) * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(l1) : "v"((tid & 255) * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:2048" : "=v"(l2) : "v"((tid & 255) * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:3072" : "=v"(l3) : "v"((tid & 255) * 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float r = l0 + l1 + l2 + l3 + lds[tid];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r += v[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) r += acc[i];
+  sink[(size_t)blockIdx.x * 256 + tid] = r;
+}
+
+hipError_t launch_calibration(int iters, float* sink, hipStream_t s) {
+  hipLaunchKernelGGL(calibration_kernel, dim3(256), dim3(256), 0, s, iters, sink);
+  return hipGetLastError();
+}
+
+}  // namespace mgs

@@ -18,7 +18,7 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
-from . import _C, _lib
+from . import _C, _lib, _state
 from .rasterizer import GaussianRasterizationSettings, _EMPTY
 
 _F32 = torch.float32
@@ -71,44 +71,70 @@ class _RasterizeViews(torch.autograd.Function):
             if P == 0:
                 out_color.zero_()
                 out_feat.zero_()
-            st = _C._dev_state(dev)
+            st = _state.device_state(dev)
+            capturing = _C._capturing()
+            if not capturing:
+                st.drain()
             key = ("views", V, P, W, H, F)
-            cap = _C._capacity_guess(st, key, V * P)
+            opts = dict(_lib.DEFAULT_OPTIONS)
+            guess = st.guess(key)
+            lazy = guess is not None and _state.forward_mode() == "async" and opts["bin_mode"] == 1
+            if capturing and not lazy:
+                raise RuntimeError("capturing a batched forward into a HIP graph needs the asynchronous path: run this "
+                                   "shape eagerly (twice) first so that its workspace sizes are known")
+            if lazy:
+                cap, pool = guess
+            else:
+                m = st.marks.get(key)
+                cap, pool = (m[0] + m[0] // 4 + 4096 if m else 4 * V * P + 4096), 0
             geom = torch.empty((L.mgs_views_geom_bytes(P, M, W, H, V),), **u8)
             img = torch.empty((L.mgs_views_img_bytes(W, H, V),), **u8)
             want = any(ctx.needs_input_grad[:9]) and P > 0
             grad_buffer = None
             a = _lib.MgsRasterArgs()
-            R = 0
+            handle = 0
+            binning = _EMPTY
             while P > 0:
-                binning = torch.empty((L.mgs_views_binning_bytes(cap, W, H, F, V),), **u8)
+                binning = torch.empty((L.mgs_views_binning_bytes2(cap, pool, W, H, F, V),), **u8)
                 _C._fill_args(a, P=P, D=int(s0.sh_degree), M=M, F=F, W=W, H=H, tanfovx=0.0, tanfovy=0.0,
                               scale_modifier=float(s0.scale_modifier), prefiltered=s0.prefiltered, debug=False,
                               include_feature=inc, background=bg, means3D=means3D, sh=sh, colors=colors_precomp,
                               language_feature=language_feature, opacity=opacities, scales=scales, rotations=rotations,
                               cov3D_precomp=cov3D_precomp, viewmatrix=None, projmatrix=None, campos=None, geom=geom,
                               binning=binning, img=img)
-                if want:
+                _lib.fill_options(a, opts)
+                slot_ptr, tag = st.take_slot()
+                a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = cap, pool, tag, 1 if lazy else 0
+                if want and grad_buffer is None:
                     sizes, accum_bytes = _layout(L, P, M, F, V, colors_precomp.numel() != 0)
                     grad_buffer = torch.empty((sum(sizes),), dtype=_F32, device=dev)
+                if want:
                     a.bwd_accum, a.bwd_accum_bytes = grad_buffer.data_ptr(), accum_bytes
                 nr = ctypes.c_int32(0)
                 rc = L.mgs_rasterize_forward_views(ctypes.byref(a), V, views, radii.data_ptr(), out_color.data_ptr(),
                                                    out_feat.data_ptr() if inc else None, ctypes.byref(nr),
-                                                   st["status_ptr"], _C._stream(dev))
+                                                   slot_ptr, _C._stream(dev))
                 R = int(nr.value)
-                if rc == _lib.MGS_NEED_CAPACITY:  # the guess was too small: run the batch again with room for R
-                    cap = R + R // 4 + 4096
+                if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) the guess was too small: run the batch again with room for R
+                    st.learn(key, R)
+                    cap, pool = R + R // 4 + 4096, 0
                     continue
                 _lib.check(rc, "rasterize views")
+                pending = _state.Pending(a, V, slot_ptr, key, captured=capturing)
+                if capturing:
+                    st.captured.append(pending)
+                else:
+                    if R >= 0:
+                        st.learn(key, R)
+                    st.pending.append(pending)
+                handle = _C.ForwardHandle(a, opts, pending, R, (views, language_feature))
                 break
-            _C._remember_capacity(st, key, R)
-        ctx.settings, ctx.num_rendered, ctx.dims = settings, R, (P, M, F, F_user, V, H, W)
+        ctx.settings, ctx.num_rendered, ctx.dims = settings, handle, (P, M, F, F_user, V, H, W)
         ctx.grad_buffer = grad_buffer
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, language_feature if inc else _EMPTY, means3D, scales, rotations,
-                              cov3D_precomp, radii, sh, geom, binning if P > 0 else _EMPTY, img, bg, *keep)
+                              cov3D_precomp, radii, sh, geom, binning, img, bg, *keep)
         if inc and F != F_user:
             out_feat = out_feat[:, :F_user].contiguous()
         return out_color, out_feat, radii
@@ -142,21 +168,11 @@ class _RasterizeViews(torch.autograd.Function):
             flat = grad_buffer if prezeroed else torch.empty((sum(sizes),), dtype=_F32, device=dev)
             (scratch, d_colors, d_feat, d_means3D, d_means2D, d_opacity, d_cov3D, d_sh, d_scales, d_rot,
              _pad) = flat.split_with_sizes(sizes)
-            views = (_lib.MgsView * V)()
-            for v, s in enumerate(settings):
-                vm, pm, cp = cams[3 * v], cams[3 * v + 1], cams[3 * v + 2]
-                views[v].tanfovx, views[v].tanfovy = float(s.tanfovx), float(s.tanfovy)
-                views[v].viewmatrix, views[v].projmatrix, views[v].campos = vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
-            a = _lib.MgsRasterArgs()
-            _C._fill_args(a, P=P, D=int(s0.sh_degree), M=M, F=F, W=W, H=H, tanfovx=0.0, tanfovy=0.0,
-                          scale_modifier=float(s0.scale_modifier), prefiltered=False, debug=False, include_feature=inc,
-                          background=bg, means3D=means3D, sh=sh, colors=colors_precomp,
-                          language_feature=language_feature, opacity=None, scales=scales, rotations=rotations,
-                          cov3D_precomp=cov3D_precomp, viewmatrix=None, projmatrix=None, campos=None, geom=geom,
-                          binning=binning, img=img)
+            handle = ctx.num_rendered
+            a, views = handle.a, handle.keep[0]  # the forward's arguments (their tensors are saved in ctx / handle.keep)
             a.accum_prezeroed = 1 if prezeroed else 0
             _lib.check(L.mgs_rasterize_backward_views(
-                ctypes.byref(a), V, views, int(ctx.num_rendered), radii.data_ptr(), g_color.data_ptr(),
+                ctypes.byref(a), V, views, handle.num_rendered_nowait(), radii.data_ptr(), g_color.data_ptr(),
                 g_feat.data_ptr() if inc else None, d_means2D.data_ptr(), None, d_opacity.data_ptr(),
                 d_colors.data_ptr(), d_feat.data_ptr() if inc else None, d_means3D.data_ptr(), d_cov3D.data_ptr(),
                 _C._ptr(d_sh), d_scales.data_ptr(), d_rot.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,

@@ -1,4 +1,4 @@
-"""Phase timeline of the dense forward at C3 (diagnostic): python scripts/trace_fwd.py [dense_variant]"""
+"""Phase timeline of the render forward at C3 (diagnostic): python scripts/trace_fwd.py"""
 import ctypes
 import os
 import sys
@@ -10,14 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
 from manigaussian_amd import synthetic as syn
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 dev = torch.device("cuda:0")
 P, F, W = 100000, 32, 128
 sc = {k: v.to(dev) for k, v in syn.make_scene(P, F=F, M=4, seed=0).items()}
 cam = syn.circle_cameras(8, W, W, negative_focal=True)[0]
 rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
-_lib.set_option("fwd_mode", 2)
-_lib.set_option("dense_variant", variant)
 
 
 def fwd():

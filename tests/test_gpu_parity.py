@@ -34,10 +34,19 @@ def _need_gpu():
 
 
 def _check(case, tight_bins=None):
+    if tight_bins is None:
+        return _check_(case)
+    old = _lib.get_option("tight_bins")
+    try:  # a per-call option: only the default the shim copies into each call is switched, and put back
+        _lib.set_option("tight_bins", tight_bins)
+        return _check_(case)
+    finally:
+        _lib.set_option("tight_bins", old)
+
+
+def _check_(case):
     case = dict(case)
     max_fragile = case.pop("max_fragile_gaussians", 0.05)
-    if tight_bins is not None:
-        _lib.set_option("tight_bins", tight_bins)
     sc, cam, kw, dC, dF = util.scene_case(**case)
     inc = case.get("include_feature", True)
     cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
@@ -123,36 +132,18 @@ def test_parity_with_oracle(name, tight):
     _check(CASES[name], tight_bins=tight)
 
 
-def test_reference_reduction_variant_agrees():
-    """bwd_reduce=0 (plain shuffles) and 1 (permlane-swap butterfly) are two implementations of one sum."""
-    for red in (0, 1):
-        _lib.set_option("bwd_reduce", red)
-        _check(dict(P=3000, F=32))
-    _lib.set_option("bwd_reduce", 1)
-
-
-_DEFAULTS = dict(render_mode=2, chunk=64, fwd_mode=2, dense_variant=1, bwd_mode=1, gm_waves=16, bin_mode=1, seg=2048,
-                 bin_octaves=4, exact_cull=1, fast_exp=1, tight_bins=1)
+_DEFAULTS = dict(gm_waves=16, bin_mode=1, seg=2048, exact_cull=1, fast_exp=1, tight_bins=1)
 VARIANTS = {
-    "legacy_rocprim_binning": dict(bin_mode=0),
+    "rocprim_binning": dict(bin_mode=0),
     "segments_512": dict(seg=512), "segments_1024": dict(seg=1024),
-    "depth_bucket_slices": dict(bin_mode=2, seg=512), "depth_bucket_slices_2_octaves": dict(bin_mode=2, bin_octaves=2),
-    "dense_chunks_of_32": dict(dense_variant=2),
-    "dense_gaussian_major_backward_8_waves": dict(gm_waves=8),
-    "entry_chunks_lds_rows": dict(fwd_mode=1),
-    "entry_chunks_pixel_major_backward": dict(fwd_mode=1, bwd_mode=0),
-    "entry_chunks_gaussian_major_backward_8_waves": dict(fwd_mode=1, gm_waves=8),
-    "original_forward": dict(fwd_mode=0),
-    "chunk_128_generic_kernels": dict(chunk=128),
-    "per_block_walk": dict(render_mode=0),
-    "chunk_items": dict(render_mode=1, chunk=128),
+    "backward_8_waves": dict(gm_waves=8),
     "ocml_expf_bbox_cull": dict(fast_exp=0, exact_cull=0),
 }
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_kernel_variants_agree_with_oracle(name):
-    """Every A/B switch (mgs_set_option) selects another implementation of the same result contract."""
+    """Every per-call switch (MgsOptions) selects another implementation of the same result contract."""
     try:
         for k, v in VARIANTS[name].items():
             _lib.set_option(k, v)
@@ -163,31 +154,33 @@ def test_kernel_variants_agree_with_oracle(name):
             _lib.set_option(k, v)
 
 
+def _raw_forward(d, kwd, P, F, W=128, H=128):
+    from manigaussian_amd import _C
+    e = torch.Tensor([])
+    return _C.rasterize_gaussians(kwd["bg"], d["means3D"], e, d["language_feature"], d["opacities"], d["scales"],
+                                  d["rotations"], 1.0, e, kwd["viewmatrix"], kwd["projmatrix"], kwd["tanfovx"],
+                                  kwd["tanfovy"], H, W, d["shs"], 1, kwd["campos"], False, False, True)
+
+
 def test_capacity_retry_and_two_call_path_match_fused_forward():
     """The fused forward sizes the binning workspace from a guess; when the guess is too small it reports
     MGS_NEED_CAPACITY and the shim re-bins with the exact count.  The reference-shaped two-call path
     (preprocess -> host read-back -> render) must give the same images as both."""
     import ctypes
-    from manigaussian_amd import _C
+    from manigaussian_amd import _C, _state
     dev = torch.device("cuda:0")
     sc, cam, kw, dC, dF = util.scene_case(P=5000, F=32)
     d = {k: v.to(dev) for k, v in sc.items()}
     kwd = syn.camera_settings_kwargs(cam, 1, True, bg=(0.1, 0.2, 0.3), device=dev)
     e = torch.Tensor([])
-
-    def fwd():
-        return _C.rasterize_gaussians(kwd["bg"], d["means3D"], e, d["language_feature"], d["opacities"], d["scales"],
-                                      d["rotations"], 1.0, e, kwd["viewmatrix"], kwd["projmatrix"], kwd["tanfovx"],
-                                      kwd["tanfovy"], 128, 128, d["shs"], 1, kwd["campos"], False, False, True)
-
-    R0, c0, f0, r0 = fwd()[:4]
-    st = _C._dev_state(dev)
+    R0, c0, f0, r0 = _raw_forward(d, kwd, 5000, 32)[:4]
+    st = _state.device_state(dev)
     key = (5000, 128, 128, 32)
-    assert st["cap"][key] >= R0
-    st["cap"][key] = 64                      # far too small: forces the retry
-    R1, c1, f1, r1 = fwd()[:4]
+    assert st.marks[key][0] >= R0
+    st.marks[key] = [16, None]               # far too small: forces the retry (blocking entry point)
+    R1, c1, f1, r1 = _raw_forward(d, kwd, 5000, 32)[:4]
     assert R1 == R0 and torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
-    assert st["cap"][key] >= R0              # the high-water mark was learnt again
+    assert st.marks[key][0] >= R0            # the high-water mark was learnt again
     # two-call path through the C ABI
     L = _lib.lib()
     u8 = dict(dtype=torch.uint8, device=dev)
@@ -199,7 +192,7 @@ def test_capacity_retry_and_two_call_path_match_fused_forward():
                   means3D=d["means3D"], sh=d["shs"], colors=e, language_feature=d["language_feature"],
                   opacity=d["opacities"], scales=d["scales"], rotations=d["rotations"], cov3D_precomp=e,
                   viewmatrix=kwd["viewmatrix"], projmatrix=kwd["projmatrix"], campos=kwd["campos"], geom=geom,
-                  binning=None, img=img)
+                  binning=None, img=img)   # a zero-initialised MgsOptions: all defaults
     radii = torch.empty(5000, dtype=torch.int32, device=dev)
     nr = ctypes.c_int32(0)
     _lib.check(L.mgs_rasterize_forward_preprocess(ctypes.byref(a), radii.data_ptr(), ctypes.byref(nr), None), "pre")
@@ -215,6 +208,137 @@ def test_capacity_retry_and_two_call_path_match_fused_forward():
     a.binning_bytes = L.mgs_binning_bytes(nr.value // 2, 128, 128, 32)
     assert L.mgs_rasterize_forward_render(ctypes.byref(a), nr.value, radii.data_ptr(), c2.data_ptr(), f2.data_ptr(),
                                           None) == _lib.MGS_ERR_WORKSPACE
+    # ... and so is an explicit (capacity, pool) pair that does not fit the buffer
+    a.binning_bytes = binning.numel()
+    a.binning_capacity, a.chunk_pool = nr.value * 4, 0
+    assert L.mgs_rasterize_forward_render(ctypes.byref(a), nr.value, radii.data_ptr(), c2.data_ptr(), f2.data_ptr(),
+                                          None) == _lib.MGS_ERR_WORKSPACE
+
+
+def _train_step(d, rast, dC, dF):
+    leaves = {k: v.detach().requires_grad_(True) for k, v in d.items()}
+    c, f, r = rast(leaves["means3D"], torch.zeros_like(leaves["means3D"]), leaves["opacities"], shs=leaves["shs"],
+                   language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                   rotations=leaves["rotations"])
+    grads = torch.autograd.grad([c, f], list(leaves.values()), [dC, dF])
+    return c, f, r, grads
+
+
+def test_async_forward_equals_blocking_forward_and_never_synchronises():
+    """Steady state (third call of a shape onwards): the forward returns without reading anything back -- the workspace
+    comes from the high-water marks, the chunk pool is a fraction of the worst case -- and images / gradients are bit
+    for bit those of the blocking path (same kernels, same order; only the record indices differ)."""
+    import manigaussian_amd as mg
+    from manigaussian_amd import _state
+    dev = torch.device("cuda:0")
+    P, F, W = 30000, 32, 128
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    dC, dF = dC.to(dev), dF.to(dev)
+    mg.set_forward_mode("blocking")
+    try:
+        c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
+        torch.cuda.synchronize()
+    finally:
+        mg.set_forward_mode("async")
+    st = _state.device_state(dev)
+    key = (P, W, W, F)
+    for _ in range(3):  # learn both marks (the chunk-record mark arrives with the render's report)
+        _train_step(d, rast, dC, dF)
+        mg.check_status(dev)
+    R_mark, chunk_mark = st.marks[key]
+    assert chunk_mark is not None and 0 < chunk_mark < _lib.lib().mgs_chunk_pool_max(R_mark, W, W) // 2
+    # the asynchronous step: enqueue a long-running kernel first; the forward must return while it is still running
+    spin = torch.empty(64 << 20, device=dev)
+    ev = torch.cuda.Event()
+    for _ in range(20):
+        spin.add_(1.0)
+    c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
+    ev.record()
+    returned_early = not ev.query()   # fwd + bwd were enqueued behind ~20 big fills and we are already back
+    torch.cuda.synchronize()
+    mg.check_status(dev)
+    assert returned_early, "the forward waited for the device"
+    assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12  # float atomics: order differs run to run
+
+
+def test_async_overflow_is_reported_loudly_and_recovers():
+    """A scene that outgrows the marks of its shape: the asynchronous forward renders garbage, the next call into the
+    library raises, and after that the shape renders correctly again."""
+    import manigaussian_amd as mg
+    from manigaussian_amd import _state
+    dev = torch.device("cuda:0")
+    P, F, W = 8000, 3, 128
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    dC, dF = dC.to(dev), dF.to(dev)
+    for _ in range(3):
+        c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
+        mg.check_status(dev)
+    st = _state.device_state(dev)
+    key = (P, W, W, F)
+    good = list(st.marks[key])
+    for bad in ([64, good[1]], [good[0], 1]):   # too few instances / too few chunk records
+        st.marks[key] = list(bad)
+        _train_step(d, rast, dC, dF)
+        with pytest.raises(RuntimeError, match="outgrew the workspace"):
+            mg.check_status(dev)
+        for _ in range(3):
+            c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
+            mg.check_status(dev)
+        assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+        assert st.marks[key][0] >= good[0] and st.marks[key][1] is not None and st.marks[key][1] >= good[1]
+
+
+def test_forward_backward_captured_into_a_hip_graph_replays_bit_identically():
+    """fwd + bwd through the public autograd API captured with torch.cuda.graph: no host synchronisation inside the
+    library, so the capture succeeds; replays reproduce the eager images bit for bit, follow in-place parameter updates,
+    and report through check_status()."""
+    import manigaussian_amd as mg
+    dev = torch.device("cuda:0")
+    P, F, W = 20000, 32, 128
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    dC, dF = dC.to(dev), dF.to(dev)
+    m2 = torch.zeros(P, 3, device=dev)
+
+    def step():
+        c, f, r = rast(leaves["means3D"], m2, leaves["opacities"], shs=leaves["shs"],
+                       language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                       rotations=leaves["rotations"])
+        return (c, f, r) + torch.autograd.grad([c, f], list(leaves.values()), [dC, dF])
+
+    for _ in range(3):
+        eager = step()
+        mg.check_status(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                   # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    mg.check_status(dev)
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1]) and torch.equal(out[2], eager[2])
+    for a, b in zip(out[3:], eager[3:]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12
+    # the graph reads the parameters where they live: an in-place update is seen by the next replay
+    with torch.no_grad():
+        leaves["means3D"].add_(0.01)
+    graph.replay()
+    torch.cuda.synchronize()
+    moved = step()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], moved[0]) and torch.equal(out[2], moved[2]) and not torch.equal(moved[0], eager[0])
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -412,35 +536,27 @@ def test_full_size_properties(P, W):
         assert (gp[k] - g1[k][perm]).abs().max().item() <= GRAD_TOL * g1[k].abs().max().item(), k
 
 
-@pytest.mark.parametrize("render_mode", [0, 2], ids=["whole_list_walk", "cooperative_chunks"])
-def test_tight_bins_is_result_preserving_at_full_size(render_mode):
+def test_tight_bins_is_result_preserving_at_full_size():
     """Dropping the (Gaussian, tile) instances whose alpha >= 1/255 footprint misses the tile removes only pairs
-    that every pixel of the tile skips: the same pairs are blended in the same order.  With the whole-list walk
-    that is bit-identical; with the chunk-parallel render the chunk boundaries move with the list, so the partial
-    sums are grouped differently and equality holds to float rounding."""
+    that every pixel of the tile skips: the same pairs are blended in the same order.  The chunk boundaries move with
+    the list, so the partial sums are grouped differently and equality holds to float rounding."""
     d, rast, cam = _full()
     dev = d["means3D"].device
     g = torch.Generator().manual_seed(9)
     dC, dF = torch.randn(3, 128, 128, generator=g).to(dev), torch.randn(32, 128, 128, generator=g).to(dev)
-    old_mode = _lib.get_option("render_mode")
     try:
-        _lib.set_option("render_mode", render_mode)
         _lib.set_option("tight_bins", 0)
         c0, f0, r0, g0 = _fwd_bwd(d, rast, dC, dF)
         _lib.set_option("tight_bins", 1)
         c1, f1, r1, g1 = _fwd_bwd(d, rast, dC, dF)
     finally:
-        _lib.set_option("render_mode", old_mode)
         _lib.set_option("tight_bins", 1)
     assert torch.equal(r0, r1)
-    if render_mode == 0:
-        assert torch.equal(c0, c1) and torch.equal(f0, f1)
-    else:
-        # regrouped products differ in the last bits; a pixel sitting on the T < 1e-4 stop rule may then keep or drop
-        # ONE more Gaussian (weight <= alpha * 1e-4): bulk at rounding level, outliers bounded by that weight
-        for x0, x1 in ((c0, c1), (f0, f1)):
-            e = (x0 - x1).abs().flatten()
-            assert torch.quantile(e[:: max(1, e.numel() // 1000000)], 0.999).item() <= 2e-6 and e.max().item() <= 1e-4
+    # regrouped products differ in the last bits; a pixel sitting on the T < 1e-4 stop rule may then keep or drop
+    # ONE more Gaussian (weight <= alpha * 1e-4): bulk at rounding level, outliers bounded by that weight
+    for x0, x1 in ((c0, c1), (f0, f1)):
+        e = (x0 - x1).abs().flatten()
+        assert torch.quantile(e[:: max(1, e.numel() // 1000000)], 0.999).item() <= 2e-6 and e.max().item() <= 1e-4
     for k in g0:
         assert (g0[k] - g1[k]).abs().max().item() <= 2e-5 * g0[k].abs().max().item() + 1e-9, k
 
