@@ -181,12 +181,13 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
             torch.zeros((1,), dtype=_F32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)  # written for every Gaussian by the preprocess
-        key = (P, W, H, F)
         opts = dict(_lib.DEFAULT_OPTIONS)
+        key = (P, W, H, F, opts["tight_bins"])
         T = ((W + 15) // 16) * ((H + 15) // 16)
         guess = st.guess(key)
-        lazy = (guess is not None and not blocking and not debug and _state.forward_mode() == "async"
-                and opts["bin_mode"] == 1 and T <= 4096)
+        # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
+        lazy = (guess is not None and not blocking and not debug and not prefiltered and
+                _state.forward_mode() == "async" and opts["bin_mode"] == 1 and T <= 4096)
         if capturing and not lazy:
             raise RuntimeError("capturing a rasterizer forward into a HIP graph needs the asynchronous path: run this shape "
                                "eagerly (twice) first so that its workspace sizes are known, with debug=False")
@@ -296,6 +297,8 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
         if handle is not None:  # the forward's arguments, as they were (same tensors: they are saved in the autograd ctx)
             a = handle.a
             count = handle.num_rendered_nowait()
+            if handle.pending is not None and handle.pending.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
+                _state.device_state(dev).drain()  # the forward of this backward overflowed its workspace: say so, loudly
         else:
             means3D = _f32c(means3D, "means3D", dev)
             colors = _f32c(colors, "colors_precomp", dev)

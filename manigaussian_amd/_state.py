@@ -120,24 +120,28 @@ class DeviceState:
 
     # ---- reports --------------------------------------------------------------------------------------------------
     def drain(self, wait=False):
-        """Read every report that has arrived (wait=True: all of them).  Raises if a forward overflowed its workspace."""
+        """Read every report that has arrived (wait=True: all of them, synchronising with the device once if one is still
+        outstanding).  Raises if a forward overflowed its workspace or finished without reporting."""
         if not self.pending:
             return
         failed = None
+        synced = False
         with self.lock:
             keep = collections.deque()
             while self.pending:
                 p = self.pending.popleft()
                 rc = p.poll()
-                while rc == _lib.MGS_PENDING and wait:
-                    rc = p.poll()
-                if rc == _lib.MGS_PENDING:
-                    if len(self.pending) + len(keep) >= NSLOTS // 2:  # the ring would wrap: this one must finish first
+                if rc == _lib.MGS_PENDING and (wait or len(self.pending) + len(keep) >= NSLOTS // 2):
+                    if not synced:  # everything enqueued so far has run after this: a report that is still missing never comes
                         torch.cuda.synchronize(self.dev)
-                        rc = p.poll()
-                    else:
-                        keep.append(p)
+                        synced = True
+                    rc = p.poll()
+                    if rc == _lib.MGS_PENDING:
+                        failed = failed or "a rasterizer forward finished without reporting its instance count"
                         continue
+                if rc == _lib.MGS_PENDING:
+                    keep.append(p)
+                    continue
                 failed = self._account(p, rc) or failed
             self.pending = keep
         if failed:
@@ -187,7 +191,5 @@ def check_status(device=None, wait=True):
     for dev, st in list(_STATES.items()):
         if device is not None and torch.device(device) != dev:
             continue
-        if wait and st.pending:
-            torch.cuda.synchronize(dev)
         st.drain(wait=wait)
         st.check_captured()

@@ -69,11 +69,11 @@ struct StageTimer {  // RAII: records start now, stop at scope exit
     Profiler& p = profiler();
     std::lock_guard<std::mutex> lk(p.mu);
     e0 = p.get(); e1 = p.get();
-    if (e0 && e1) hipEventRecord(e0, stream); else e0 = e1 = nullptr;
+    if (e0 && e1) (void)hipEventRecord(e0, stream); else e0 = e1 = nullptr;
   }
   ~StageTimer() {
     if (!e0) return;
-    hipEventRecord(e1, stream);
+    (void)hipEventRecord(e1, stream);
     Profiler& p = profiler();
     std::lock_guard<std::mutex> lk(p.mu);
     p.used[stage].push_back({e0, e1});
@@ -434,8 +434,13 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
     if (rc) return rc;
     *num_rendered = (int32_t)R;
     if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
-    // word 1 (chunk-pool report) still comes from the render kernel when there is a status block
-    if (host_status) { volatile uint64_t* hs = host_status; hs[0] = kStatusPending; hs[1] = kStatusPending; }
+    // word 1 (chunk-pool report) still comes from the render kernel when there is a status block; word 0 is known here
+    // (the rocPRIM binning has no kernel that would report it)
+    if (host_status) {
+      volatile uint64_t* hs = host_status;
+      hs[1] = kStatusPending;
+      hs[0] = ((uint64_t)(a->status_tag & 0xffffu) << 48) | ((uint64_t)(fl & 0xffffu) << 32) | R;
+    }
     return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, stream);
   }
   // sync-free: everything is enqueued; the binning kernel stores {tag, flags, R} to the mapped host word as soon as the
@@ -814,7 +819,7 @@ int mgs_selftest(mgs_stream_t stream_) {
   if (e == hipSuccess) e = launch_selftest(d, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  hipFree(d);
+  (void)hipFree(d);
   MGS_HIP(e, "selftest");
   if (h != 0) { set_error("wave64 primitive self-test failed, mask 0x%x", h); return h; }
   return MGS_OK;

@@ -23,13 +23,13 @@ namespace mgs {
 
 size_t scan_temp_bytes(int P) {
   size_t bytes = 0;
-  hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, P);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, P);
   return bytes + 256;
 }
 
 size_t sort_temp_bytes(int R) {
   size_t bytes = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                      (uint32_t*)nullptr, R);
   return bytes + 256;
 }

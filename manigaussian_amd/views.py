@@ -75,10 +75,11 @@ class _RasterizeViews(torch.autograd.Function):
             capturing = _C._capturing()
             if not capturing:
                 st.drain()
-            key = ("views", V, P, W, H, F)
             opts = dict(_lib.DEFAULT_OPTIONS)
+            key = ("views", V, P, W, H, F, opts["tight_bins"])
             guess = st.guess(key)
-            lazy = guess is not None and _state.forward_mode() == "async" and opts["bin_mode"] == 1
+            lazy = (guess is not None and _state.forward_mode() == "async" and opts["bin_mode"] == 1
+                    and not s0.prefiltered)
             if capturing and not lazy:
                 raise RuntimeError("capturing a batched forward into a HIP graph needs the asynchronous path: run this "
                                    "shape eagerly (twice) first so that its workspace sizes are known")
@@ -170,9 +171,12 @@ class _RasterizeViews(torch.autograd.Function):
              _pad) = flat.split_with_sizes(sizes)
             handle = ctx.num_rendered
             a, views = handle.a, handle.keep[0]  # the forward's arguments (their tensors are saved in ctx / handle.keep)
+            count = handle.num_rendered_nowait()
+            if handle.pending is not None and handle.pending.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
+                _state.device_state(dev).drain()  # the forward of this backward overflowed its workspace: say so, loudly
             a.accum_prezeroed = 1 if prezeroed else 0
             _lib.check(L.mgs_rasterize_backward_views(
-                ctypes.byref(a), V, views, handle.num_rendered_nowait(), radii.data_ptr(), g_color.data_ptr(),
+                ctypes.byref(a), V, views, count, radii.data_ptr(), g_color.data_ptr(),
                 g_feat.data_ptr() if inc else None, d_means2D.data_ptr(), None, d_opacity.data_ptr(),
                 d_colors.data_ptr(), d_feat.data_ptr() if inc else None, d_means3D.data_ptr(), d_cov3D.data_ptr(),
                 _C._ptr(d_sh), d_scales.data_ptr(), d_rot.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,

@@ -10,8 +10,9 @@ for W in tests bench stats pmc configs; do
   want "$@" || continue
   case $W in
   tests)
-    timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-    tail -25 $OUT/pytest_gpu.log ;;
+    timeout 900 python -m pytest tests -m gpu -q --maxfail 6 --durations=8 --timeout 180 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+    tail -25 $OUT/pytest_gpu.log
+    for PP in 20000 100000; do timeout 120 python tests/tools/graph_capture_check.py $PP > $OUT/graph_check_$PP.log 2>&1; echo "graph check P=$PP rc=$?"; grep -v "^  File\|^$" $OUT/graph_check_$PP.log | head -12; done ;;
   bench)
     timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"
     tail -1 $OUT/bench.log | cut -c1-3000 ;;

@@ -175,7 +175,7 @@ def test_capacity_retry_and_two_call_path_match_fused_forward():
     e = torch.Tensor([])
     R0, c0, f0, r0 = _raw_forward(d, kwd, 5000, 32)[:4]
     st = _state.device_state(dev)
-    key = (5000, 128, 128, 32)
+    key = (5000, 128, 128, 32, 1)
     assert st.marks[key][0] >= R0
     st.marks[key] = [16, None]               # far too small: forces the retry (blocking entry point)
     R1, c1, f1, r1 = _raw_forward(d, kwd, 5000, 32)[:4]
@@ -243,7 +243,7 @@ def test_async_forward_equals_blocking_forward_and_never_synchronises():
     finally:
         mg.set_forward_mode("async")
     st = _state.device_state(dev)
-    key = (P, W, W, F)
+    key = (P, W, W, F, 1)
     for _ in range(3):  # learn both marks (the chunk-record mark arrives with the render's report)
         _train_step(d, rast, dC, dF)
         mg.check_status(dev)
@@ -280,13 +280,13 @@ def test_async_overflow_is_reported_loudly_and_recovers():
         c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
         mg.check_status(dev)
     st = _state.device_state(dev)
-    key = (P, W, W, F)
+    key = (P, W, W, F, 1)
     good = list(st.marks[key])
     for bad in ([64, good[1]], [good[0], 1]):   # too few instances / too few chunk records
         st.marks[key] = list(bad)
-        _train_step(d, rast, dC, dF)
         with pytest.raises(RuntimeError, match="outgrew the workspace"):
-            mg.check_status(dev)
+            _train_step(d, rast, dC, dF)   # the backward may already know (the report arrived) ...
+            mg.check_status(dev)           # ... the next synchronisation point knows for sure
         for _ in range(3):
             c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
             mg.check_status(dev)
@@ -295,50 +295,14 @@ def test_async_overflow_is_reported_loudly_and_recovers():
 
 
 def test_forward_backward_captured_into_a_hip_graph_replays_bit_identically():
-    """fwd + bwd through the public autograd API captured with torch.cuda.graph: no host synchronisation inside the
-    library, so the capture succeeds; replays reproduce the eager images bit for bit, follow in-place parameter updates,
-    and report through check_status()."""
-    import manigaussian_amd as mg
-    dev = torch.device("cuda:0")
-    P, F, W = 20000, 32, 128
-    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
-    leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
-    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
-    dC, dF = dC.to(dev), dF.to(dev)
-    m2 = torch.zeros(P, 3, device=dev)
-
-    def step():
-        c, f, r = rast(leaves["means3D"], m2, leaves["opacities"], shs=leaves["shs"],
-                       language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
-                       rotations=leaves["rotations"])
-        return (c, f, r) + torch.autograd.grad([c, f], list(leaves.values()), [dC, dF])
-
-    for _ in range(3):
-        eager = step()
-        mg.check_status(dev)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        step()                                   # warm-up on the capture stream
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = step()
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    mg.check_status(dev)
-    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1]) and torch.equal(out[2], eager[2])
-    for a, b in zip(out[3:], eager[3:]):
-        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12
-    # the graph reads the parameters where they live: an in-place update is seen by the next replay
-    with torch.no_grad():
-        leaves["means3D"].add_(0.01)
-    graph.replay()
-    torch.cuda.synchronize()
-    moved = step()
-    torch.cuda.synchronize()
-    assert torch.equal(out[0], moved[0]) and torch.equal(out[2], moved[2]) and not torch.equal(moved[0], eager[0])
+    """fwd + bwd through the public autograd API captured with torch.cuda.graph (tests/tools/graph_capture_check.py, in a
+    process of its own: stream capture is process-wide state): the capture succeeds because the library never
+    synchronises, replays reproduce the eager images bit for bit and follow in-place parameter updates."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "tools", "graph_capture_check.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -364,21 +328,40 @@ def test_golden_vectors(path):
             assert e.max() <= util.FRAGILE_GRAD_TOL * np.abs(ref).max() + 1e-7, k
 
 
-def _check_against_reference(got, ref, inc, tag):
-    """got / ref = (color, feat, radii, grads by Oracle-B name).  Both sides ran on gfx950 with the same exp(), so even
-    threshold-fragile pixels agree: radii bit-exact, images 2e-5 everywhere, gradients 1e-3 of the tensor max (measured:
-    <= 2e-6 and <= 1e-4, profiles/r01_ref_compare.log)."""
+def _check_against_reference(got, ref, inc, tag, state=None):
+    """got / ref = (color, feat, radii, grads by Oracle-B name).  Both sides ran on gfx950: radii bit-exact, images 2e-5,
+    gradients 1e-3 of the tensor max (measured: <= 2e-6 and <= 1e-4, profiles/r01_ref_compare.log).
+    state (an Oracle-B run of the same scene): the library evaluates exp() with v_exp_f32 (relative error ~2e-7), the
+    reference with ocml's expf, so a (pixel, Gaussian) pair within that distance of a hard threshold (alpha < 1/255,
+    T < 1e-4) may be decided differently -- a handful of pairs among the 10^8..10^9 of the large cases.  The pixels /
+    Gaussians Oracle B marks as sitting within 2e-5 (relative) of such a threshold get FRAGILE_TOL / FRAGILE_GRAD_TOL;
+    everything else the strict bound."""
     (ch, fh, rh, gh), (cr, fr, rr, gr) = got, ref
     assert np.array_equal(np.asarray(rh), np.asarray(rr)), tag
-    assert np.abs(np.asarray(ch) - np.asarray(cr)).max() <= 2e-5, tag
-    if inc:
-        assert np.abs(np.asarray(fh) - np.asarray(fr)).max() <= 2e-5, tag
+    frag_px = frag_g = None
+    if state is not None:
+        from oracle import oracle_b
+        frag_px, frag_g = oracle_b.fragile_mask(state).numpy(), oracle_b.fragile_gaussians(state).numpy()
+        assert frag_px.mean() <= util.FRAGILE_MAX_FRACTION, tag
+    for a, b in [(ch, cr)] + ([(fh, fr)] if inc else []):
+        e = np.abs(np.asarray(a) - np.asarray(b)).max(0)
+        if frag_px is None:
+            assert e.max() <= 2e-5, tag
+        else:
+            assert e[~frag_px].max() <= 2e-5, tag
+            assert e.max() <= util.FRAGILE_TOL, tag
     for k, v in gh.items():
         r = np.asarray(gr[util.GRAD_KEYS[k]])
         if k == "language_feature" and not inc:
             continue
         if r.size:
-            assert np.abs(v.numpy() - r.reshape(v.shape)).max() <= GRAD_TOL * np.abs(r).max() + 1e-7, (tag, k)
+            e = np.abs(v.numpy() - r.reshape(v.shape)).reshape(v.shape[0], -1).max(1)
+            mag = np.abs(r).max()
+            if frag_g is None:
+                assert e.max() <= GRAD_TOL * mag + 1e-7, (tag, k)
+            else:
+                assert e[~frag_g].max() <= GRAD_TOL * mag + 1e-7, (tag, k)
+                assert e.max() <= util.FRAGILE_GRAD_TOL * mag + 1e-7, (tag, k)
 
 
 @pytest.mark.parametrize("path", REF_GOLDEN, ids=[os.path.basename(p)[:-4] for p in REF_GOLDEN])
@@ -417,7 +400,8 @@ def test_live_reference(case):
     inc = case.get("include_feature", True)
     cr, fr, rr, gr, R = util.run_reference(sc, kw, dC, dF)
     got = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case.get("bg", (0.1, 0.2, 0.3)))
-    _check_against_reference(got, (cr, fr, rr, gr), inc, repr(case))
+    state = util.run_oracle_b(sc, kw, dC, dF)[4]  # only to know which pixels sit on a hard threshold
+    _check_against_reference(got, (cr, fr, rr, gr), inc, repr(case), state=state)
 
 
 def test_edge_cases_empty_and_all_culled():
@@ -678,19 +662,29 @@ def test_view_batch_matches_reference_kernels(case):
     bg = (0.1, 0.2, 0.3)
     sc, cams, dC, dF = _batch_case(P, F, V, W, H)
     cb, fb, rb, gb, m2b = _run_batch(sc, cams, dC, dF, bg)
-    acc = None
+    from oracle import oracle_b
+    acc, fragile = None, torch.zeros(P, dtype=torch.bool)
     for v, cam in enumerate(cams):
         kw = syn.camera_settings_kwargs(cam, 1, True, bg=bg)
         cr, fr, rr, gr, _ = util.run_reference(sc, kw, dC[v], dF[v])
+        state = util.run_oracle_b(sc, kw, dC[v], dF[v])[4]  # which pixels / Gaussians sit on a hard threshold in this view
+        fpx, fg = oracle_b.fragile_mask(state), oracle_b.fragile_gaussians(state)
+        fragile |= fg
         assert np.array_equal(rb[v].numpy(), rr.numpy()), f"radii, view {v}"
-        assert (cb[v] - cr).abs().max().item() <= 2e-5, f"color, view {v}"
-        assert (fb[v] - fr).abs().max().item() <= 2e-5, f"feature, view {v}"
+        for nm, a, b in (("color", cb[v], cr), ("feature", fb[v], fr)):
+            e = (a - b).abs().max(0)[0]
+            assert e[~fpx].max().item() <= 2e-5 and e.max().item() <= util.FRAGILE_TOL, f"{nm}, view {v}"
         r2 = gr["means2D"]
-        assert (m2b[v] - r2).abs().max().item() <= GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
+        e2 = (m2b[v] - r2).abs().max(1)[0]
+        assert e2[~fg].max().item() <= GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
+        assert e2.max().item() <= util.FRAGILE_GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
         acc = {k: t.clone() for k, t in gr.items()} if acc is None else {k: acc[k] + gr[k] for k in acc}
     for k, got in gb.items():
         ref = acc[util.GRAD_KEYS[k]].reshape(got.shape)
-        assert (got - ref).abs().max().item() <= GRAD_TOL * ref.abs().max().item() + 1e-9, k
+        d = (got - ref).abs().reshape(P, -1).max(1)[0]
+        mag = ref.abs().max().item()
+        assert d[~fragile].max().item() <= GRAD_TOL * mag + 1e-9, k
+        assert d.max().item() <= util.FRAGILE_GRAD_TOL * mag + 1e-9, k
 
 
 @pytest.mark.parametrize("case", [dict(P=6000, F=32, V=4, W=128, H=128), dict(P=3000, F=3, V=3, W=72, H=40),
