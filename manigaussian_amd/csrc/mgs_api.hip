@@ -231,7 +231,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
   segsort = segsort_binning(o, p.tiles_x * p.tiles_y);
-  MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
+  MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -356,8 +356,8 @@ static int check_render_args(const MgsRasterArgs* a, float* out_color, float* ou
   const int F = a->include_feature ? a->F : 0;
   if (F > 0 && !out_feature) { set_error("out_feature is NULL"); return MGS_ERR_INVALID_ARG; }
   if (a->P == 0) {  // rasterize_points.cu:70-92: zero-filled outputs, nothing launched
-    MGS_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream), "memset out_color");
-    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, F * N * sizeof(float), stream), "memset out_feature");
+    MGS_HIP(launch_zero_bytes(out_color, 3 * N * sizeof(float), stream), "memset out_color");
+    if (F > 0) MGS_HIP(launch_zero_bytes(out_feature, F * N * sizeof(float), stream), "memset out_feature");
     *done = true;
   }
   return MGS_OK;
@@ -530,11 +530,11 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
     const bool adj_feat = F == 0 || reinterpret_cast<char*>(dL_dfeature) == reinterpret_cast<char*>(dcol) + 3 * P * sizeof(float);
     if (adj_col && adj_feat) {
       char* end = reinterpret_cast<char*>(dcol) + (3 + (size_t)F) * P * sizeof(float);
-      MGS_HIP(hipMemsetAsync(z0, 0, (size_t)(end - z0), stream), "memset accumulators");
+      MGS_HIP(launch_zero_bytes(z0, (size_t)(end - z0), stream), "memset accumulators");
     } else {
-      MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * P * sizeof(float), stream), "memset acc8");
-      MGS_HIP(hipMemsetAsync(dcol, 0, 3 * P * sizeof(float), stream), "memset dL_dcolors");
-      if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
+      MGS_HIP(launch_zero_bytes(sc.acc8, 8 * P * sizeof(float), stream), "memset acc8");
+      MGS_HIP(launch_zero_bytes(dcol, 3 * P * sizeof(float), stream), "memset dL_dcolors");
+      if (F > 0) MGS_HIP(launch_zero_bytes(dL_dfeature, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
     } }
   if (R != 0) {  // R < 0: count unknown to the host (asynchronous forward) -- empty ranges make the kernel a no-op
     const RenderArgs r = render_args(a, o, g);
@@ -642,8 +642,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   const int F = a->include_feature ? a->F : 0;
   if (!out_color || (F > 0 && !out_feature)) { set_error("output image is NULL"); return MGS_ERR_INVALID_ARG; }
   if (a->P == 0) {
-    MGS_HIP(hipMemsetAsync(out_color, 0, (size_t)V * 3 * N * sizeof(float), stream), "memset out_color");
-    if (F > 0) MGS_HIP(hipMemsetAsync(out_feature, 0, (size_t)V * F * N * sizeof(float), stream), "memset out_feature");
+    MGS_HIP(launch_zero_bytes(out_color, (size_t)V * 3 * N * sizeof(float), stream), "memset out_color");
+    if (F > 0) MGS_HIP(launch_zero_bytes(out_feature, (size_t)V * F * N * sizeof(float), stream), "memset out_feature");
     const uint64_t w = (uint64_t)(a->status_tag & 0xffffu) << 48;
     host_status[0] = w; host_status[1] = w;
     return MGS_OK;
@@ -684,7 +684,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
   p.tile_hist = im.tile_hist; p.blk_base = g.blk_base;
-  MGS_HIP(hipMemsetAsync(im.flags, 0, im.zero_bytes, stream), "memset flags + tile tables");
+  MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;
@@ -747,9 +747,9 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
   const size_t ncol = a->colors_precomp ? P : PV;  // dL_dcolors rows: per Gaussian (precomputed colours) or per (view, Gaussian)
   if (!a->accum_prezeroed) {
     StageTimer t(ST_BWD_MEMSET, stream);
-    MGS_HIP(hipMemsetAsync(sc.acc8, 0, 8 * PV * sizeof(float), stream), "memset acc8");
-    MGS_HIP(hipMemsetAsync(dL_dcolors, 0, 3 * ncol * sizeof(float), stream), "memset dL_dcolors");
-    if (F > 0) MGS_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
+    MGS_HIP(launch_zero_bytes(sc.acc8, 8 * PV * sizeof(float), stream), "memset acc8");
+    MGS_HIP(launch_zero_bytes(dL_dcolors, 3 * ncol * sizeof(float), stream), "memset dL_dcolors");
+    if (F > 0) MGS_HIP(launch_zero_bytes(dL_dfeature, (size_t)F * P * sizeof(float), stream), "memset dL_dfeature");
   }
   if (R != 0) {
     const RenderArgs r = views_render_args(a, o, at, g);
@@ -815,7 +815,7 @@ int mgs_selftest(mgs_stream_t stream_) {
   int* d = nullptr;
   MGS_HIP(hipMalloc(&d, sizeof(int)), "hipMalloc");
   int h = 0;
-  hipError_t e = hipMemsetAsync(d, 0, sizeof(int), stream);
+  hipError_t e = launch_zero_bytes(d, sizeof(int), stream);
   if (e == hipSuccess) e = launch_selftest(d, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);

@@ -117,7 +117,7 @@ static uint32_t higher_msb(uint32_t n) {
 
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P, int R,
                             int tiles_x, int tiles_y, int tight_bins, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)tiles_x * tiles_y, s);
+  hipError_t e = launch_zero_bytes(im.ranges, sizeof(uint2) * (size_t)tiles_x * tiles_y, s);
   if (e != hipSuccess) return e;
   if (R <= 0 || P <= 0) return hipSuccess;
   hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.depths,

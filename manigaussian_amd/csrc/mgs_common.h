@@ -234,6 +234,7 @@ struct FwdPreArgs {
 };
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s);
 hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
+hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
 // Status the device reports to the host (pinned, device-mapped memory): word 0 = tag<<48 | flags<<32 | num_rendered, written
 // by the bin scatter kernel as soon as the preprocess is done; word 1 = tag<<48 | overflow<<32 | chunk records used, written
 // by the last workgroup of the render forward.  tag: 16 bits chosen by the caller (a stale write is recognisable).

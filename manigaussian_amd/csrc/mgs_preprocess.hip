@@ -267,6 +267,31 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   }
 }
 
+// Zero-fill of the small per-forward tables (flags | tile histogram | segment bases) as an ordinary kernel node: a captured
+// hipMemsetAsync node was observed to run out of order with the kernels around it when a HIP graph is replayed after other
+// work (ROCm 7.2), which corrupts the histogram; a kernel launch is ordered like every other launch of the chain.
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, size_t head, size_t n16, size_t tail) {
+  // [head words][n16 x 16 bytes][tail words]: the body is 16-byte aligned
+  uint4* __restrict__ body = reinterpret_cast<uint4*>(p + head);
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = gid; i < n16; i += gsz) body[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (gid < head) p[gid] = 0u;
+  if (gid < tail) p[head + 4 * n16 + gid] = 0u;
+}
+hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {  // p 4-byte aligned, bytes a multiple of 4
+  if (bytes == 0) return hipSuccess;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  size_t words = bytes / 4;
+  size_t head = ((16 - (a & 15u)) & 15u) / 4;
+  if (head > words) head = words;
+  const size_t n16 = (words - head) / 4, tail = (words - head) % 4;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), head, n16, tail);
+  return hipGetLastError();
+}
+
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   if (a.tile_hist)

@@ -6,13 +6,40 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 want() { for a in "$@"; do [ "$a" = "$W" ] && return 0; done; return 1; }
-for W in tests bench stats pmc configs; do
+for W in tests graph skips bisect noscratch scratch dump oob host bench stats pmc configs; do
   want "$@" || continue
   case $W in
   tests)
     timeout 900 python -m pytest tests -m gpu -q --maxfail 6 --durations=8 --timeout 180 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
     tail -25 $OUT/pytest_gpu.log
     for PP in 20000 100000; do timeout 120 python tests/tools/graph_capture_check.py $PP > $OUT/graph_check_$PP.log 2>&1; echo "graph check P=$PP rc=$?"; grep -v "^  File\|^$" $OUT/graph_check_$PP.log | head -12; done ;;
+  graph)
+    for PP in 20000; do timeout 120 python tests/tools/graph_capture_check.py $PP > $OUT/graph_check_$PP.log 2>&1; echo "graph check P=$PP rc=$?"; grep -v "^  File\|^$" $OUT/graph_check_$PP.log | head -12; done ;;
+  skips)
+    for sk in status images grads status,images,grads; do
+      MGS_GRAPH_SKIP=$sk timeout 100 python tests/tools/graph_capture_check.py 20000 > $OUT/skip_$sk.log 2>&1; echo "skip $sk rc=$? $(grep -c GRAPH_OK $OUT/skip_$sk.log) $(grep -c fault $OUT/skip_$sk.log) last: $(grep stage $OUT/skip_$sk.log | tail -1)"
+    done ;;
+  bisect)
+    for part in full; do for b in verify leafmove; do
+      timeout 100 python tests/tools/graph_bisect.py $part $b > $OUT/bisect_${part}_$b.log 2>&1; echo "bisect $part $b rc=$? $(grep -c BISECT_OK $OUT/bisect_${part}_$b.log)"; grep "replay \|eager " $OUT/bisect_${part}_$b.log
+    done; done ;;
+  noscratch)
+    # library built with -DMGS_FWD_WAVES8 in manigaussian_amd/libmgsplat_w8.so is swapped in for this check only
+    cp manigaussian_amd/libmgsplat.so /tmp/libmgsplat_keep.so; cp manigaussian_amd/libmgsplat_w8.so manigaussian_amd/libmgsplat.so
+    MGS_GM_WAVES=8 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_noscratch.log 2>&1; echo "graph no-scratch kernels rc=$?"; grep "stage\|fault\|GRAPH_OK\|Error" $OUT/graph_noscratch.log | tail -5
+    cp /tmp/libmgsplat_keep.so manigaussian_amd/libmgsplat.so ;;
+  scratch)
+    HSA_NO_SCRATCH_RECLAIM=1 MGS_GRAPH_MOVE=0.0 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_noreclaim.log 2>&1; echo "graph HSA_NO_SCRATCH_RECLAIM=1 rc=$?"; grep "stage\|fault\|GRAPH_OK\|Error" $OUT/graph_noreclaim.log | tail -5
+    HSA_NO_SCRATCH_RECLAIM=1 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_noreclaim2.log 2>&1; echo "graph HSA_NO_SCRATCH_RECLAIM=1 moved rc=$?"; grep "stage\|fault\|GRAPH_OK\|Error" $OUT/graph_noreclaim2.log | tail -5 ;;
+  dump)
+    MGS_GRAPH_DUMP=1 MGS_GRAPH_MOVE=0.0 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_dump.log 2>&1; echo "graph dump rc=$?"; grep -v "^  File" $OUT/graph_dump.log | cut -c1-600 | tail -60 ;;
+  oob)
+    # every tensor its own hipMalloc: an out-of-bounds write faults instead of landing in the caching allocator's slack
+    PYTORCH_NO_CUDA_MEMORY_CACHING=1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -p no:cacheprovider -k "parity_with_oracle or translucent or async or view_batch_matches_oracle_b or full_size" > $OUT/pytest_oob.log 2>&1; echo "oob pytest rc=$?"; tail -5 $OUT/pytest_oob.log
+    MGS_GRAPH_MOVE=0.0 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_move0.log 2>&1; echo "graph move 0 rc=$?"; grep "stage\|fault\|GRAPH_OK" $OUT/graph_move0.log | tail -4
+    MGS_GRAPH_EAGER_FIRST=1 timeout 120 python tests/tools/graph_capture_check.py 20000 > $OUT/graph_eager_first.log 2>&1; echo "graph eager-first rc=$?"; grep "stage\|fault\|GRAPH_OK" $OUT/graph_eager_first.log | tail -4 ;;
+  host)
+    timeout 300 python scripts/host_profile3.py > $OUT/host_profile.log 2>&1; echo "host rc=$?"; head -60 $OUT/host_profile.log ;;
   bench)
     timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"
     tail -1 $OUT/bench.log | cut -c1-3000 ;;

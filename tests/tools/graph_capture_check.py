@@ -19,6 +19,9 @@ import util  # noqa: E402
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 from manigaussian_amd import synthetic as syn  # noqa: E402
 
+if os.environ.get("MGS_GM_WAVES"):
+    from manigaussian_amd import _lib as _l
+    _l.set_option("gm_waves", int(os.environ["MGS_GM_WAVES"]))
 dev = torch.device("cuda:0")
 P, F, W = int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 32, 128
 sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
@@ -61,18 +64,59 @@ for _ in range(3):
     graph.replay()
 torch.cuda.synchronize()
 stage("replayed")
-mg.check_status(dev)
-assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1]) and torch.equal(out[2], eager[2]), "images differ"
-for a, b in zip(out[3:], eager[3:]):
-    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12, "gradients differ"
+SKIP = os.environ.get("MGS_GRAPH_SKIP", "")
+if "status" not in SKIP:
+    mg.check_status(dev)
+stage("status checked")
+if "images" not in SKIP:
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1]) and torch.equal(out[2], eager[2]), "images differ"
+if "grads" not in SKIP:
+    for a, b in zip(out[3:], eager[3:]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12, "gradients differ"
 # the graph reads the parameters where they live: an in-place update is seen by the next replay
+stage("replays equal the eager step")
+if os.environ.get("MGS_GRAPH_DUMP"):
+    from manigaussian_amd import _state
+    st_ = _state.device_state(dev)
+    snap = torch.cuda.memory_snapshot()
+
+    def where(ptr):
+        for seg in snap:
+            if seg["address"] <= ptr < seg["address"] + seg["total_size"]:
+                off = seg["address"]
+                for b in seg["blocks"]:
+                    if off <= ptr < off + b["size"]:
+                        return f"pool {seg.get('segment_pool_id')} {seg.get('segment_type')} block {b['state']} size {b['size']}"
+                    off += b["size"]
+        return "NOT IN ANY DEVICE SEGMENT"
+    a_ = st_.captured[0].a
+    for name in ("background", "means3D", "shs", "language_feature", "opacities", "scales", "rotations", "viewmatrix",
+                 "projmatrix", "campos", "geom", "binning", "img", "bwd_accum"):
+        v = getattr(a_, name)
+        print("arg", name, hex(v or 0), where(v or 0), flush=True)
+    for i, t in enumerate(out):
+        print("out", i, hex(t.data_ptr()), where(t.data_ptr()), flush=True)
+    print("dC", where(dC.data_ptr()), "dF", where(dF.data_ptr()), flush=True)
+MOVE = float(os.environ.get("MGS_GRAPH_MOVE", "0.01"))
+if os.environ.get("MGS_GRAPH_EAGER_FIRST"):
+    with torch.no_grad():
+        leaves["means3D"].add_(MOVE)
+    step()
+    torch.cuda.synchronize()
+    stage("eager step on moved parameters before the replay: fine")
+    with torch.no_grad():
+        leaves["means3D"].sub_(MOVE)
 with torch.no_grad():
-    leaves["means3D"].add_(0.01)
+    leaves["means3D"].add_(MOVE)
+torch.cuda.synchronize()
+stage("parameters moved")
 graph.replay()
 torch.cuda.synchronize()
+stage("replayed on the moved parameters")
 replayed = [t.clone() for t in out[:3]]
 moved = [t.detach() for t in step()]
 torch.cuda.synchronize()
+stage("eager step on the moved parameters")
 assert torch.equal(replayed[0], moved[0]) and torch.equal(replayed[2], moved[2]), "replay does not follow the parameters"
 assert not torch.equal(moved[0], eager[0])
 mg.check_status(dev)
