@@ -139,8 +139,9 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   return v;
 }
 
-// Records of the worst case: every chunk of every 8x8 block visited.
-inline uint32_t chunk_pool_max(size_t R, int T) { return (uint32_t)(4 * ((R + CHUNK - 1) / CHUNK + (size_t)T)); }
+// Records of the worst case: every chunk of every 8x8 block visited; a block takes its records 16 at a time (one round of
+// the render forward), so every block may leave up to 15 of its last round unused.
+inline uint32_t chunk_pool_max(size_t R, int T) { return (uint32_t)(4 * ((R + CHUNK - 1) / CHUNK + 16 * (size_t)T)); }
 // Entries of the (block, round) -> record table (round_entry() in mgs_render_common.h: granule 512 survivors).
 inline size_t round_table_entries(size_t R, int T) { return 4 * (R / 512 + 2 * (size_t)T + 2); }
 

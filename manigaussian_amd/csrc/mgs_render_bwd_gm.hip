@@ -154,6 +154,9 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
     const uint32_t kmax = wave_umax(last);
     if (kmax == 0) continue;
     const bool live = last > 0;
+    // pixels that blended something of group 0 / group 1 of this chunk: a pixel step whose two pixels (one per half-wave)
+    // are both dead for the group contributes exact zeros to every sum and is skipped
+    const unsigned long long lm0 = ballot(live), lm1 = ballot(last > 32u);
     float B = 0.f;
     for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
       const float v = q[slot_of(c2) * 64 + lane];
@@ -208,6 +211,8 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
       // D tile and no colour/feature row are live during the pixel steps
 #pragma unroll 1
       for (int u = 0; u < 2; u++) {
+        const uint32_t lmu = (uint32_t)((g == 0 ? lm0 : lm1) >> (32 * u));  // live pixels of this tile (block rows 4u .. 4u+3)
+        if (lmu == 0u) continue;
         // D = dL . row for my 16 pixels of this tile, on the matrix cores.  B operand: lane (n, h) feeds channel
         // 2t + h of its Gaussian's row (features, then r, g, b, zero padding), straight from memory.
         f32x16 Dt;
@@ -231,6 +236,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
         const float pyu = by0 + (float)(4 * u);
 #pragma unroll 1
         for (int rr = 0; rr < 16; rr++) {  // rolled: one pixel step's worth of registers (Dt[rr]: uniform index)
+          if (((lmu >> ((rr & 3) + 8 * (rr >> 2))) & 0x11u) == 0u) continue;  // both pixels of the step dead in this group
           const int pp = 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * h;  // my pixel of this step
           const float4 st = pd[w][pp];
           const float Tg = (g == 0) ? st.x : st.w;                   // transmittance entering this group

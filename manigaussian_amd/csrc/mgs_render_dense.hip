@@ -91,7 +91,14 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   uint32_t fill = 0;       // fill steps done (parity selects the cnt buffer)
   uint32_t round = 0;
 
+  const bool allocator = tid == (NW - 1) * 64;  // lane 0 of the last wave takes the rounds' chunk records from the pool
   for (;; round++) {
+    // This round's chunk records: NW consecutive ones (a round blends at most NW chunks; the pool is sized from what
+    // forwards actually took, so rounding up costs memory, not correctness), requested BEFORE the fill so that the
+    // returning atomic's round trip hides behind it.
+    uint32_t b0 = 0;
+    const bool more = next < rng.y || qtail > qhead;
+    if (allocator && more) b0 = atomicAdd(&flags[FLAG_CHUNKS_USED], (uint32_t)NW);
     // ---- fill: examine FILLK * FSTEP entries per step until a full round of survivors waits (or the list ends);
     //      survivors go, in list order, to this block's list in memory (read back below and by the backward) ----
     while (qtail - qhead < ROUND && next < rng.y) {
@@ -135,6 +142,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       next += FILLK * FSTEP;
       fill++;
     }
+    if (allocator && more) {
+      rbase[round & 1] = b0;
+      if (round < RBH) rb_hist[round] = b0;
+      my_rounds[4 * (size_t)round] = b0;  // for the backward
+    }
     MGS_TRACE(1 + 8 * round);
     __syncthreads();  // the list is written (workgroup scope); the previous round's Tp readers are done
     MGS_TRACE(2 + 8 * round);
@@ -143,12 +155,6 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     uint32_t nchunk = exhausted ? (avail + CHS - 1) / CHS : avail / CHS;
     nchunk = min(nchunk, (uint32_t)NW);
     if (nchunk == 0) break;
-    if (tid == 0) {  // this round's chunk records: one returning atomic, consumed after phase A (latency hidden)
-      const uint32_t b0 = atomicAdd(&flags[FLAG_CHUNKS_USED], nchunk);
-      rbase[round & 1] = b0;
-      if (round < RBH) rb_hist[round] = b0;
-      my_rounds[4 * (size_t)round] = b0;  // for the backward
-    }
     const uint32_t c = cbase + (uint32_t)w;
     const bool has = (uint32_t)w < nchunk;
     const uint32_t n_my = has ? min((uint32_t)CHS, avail - (uint32_t)w * CHS) : 0u;  // survivors of my chunk
@@ -221,7 +227,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     __syncthreads();
     MGS_TRACE(5 + 8 * round);
     const uint32_t rb = rbase[round & 1];
-    if (rb + nchunk > pool) { overflow = true; break; }  // uniform: every thread reads the same word
+    if (rb + (uint32_t)NW > pool) { overflow = true; break; }  // uniform: every thread reads the same word
     // ---- prefix in chunk order (identical arithmetic in every wave) ----
     float T = Tround, Tnext = Tround;
 #pragma unroll
@@ -335,6 +341,15 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   }
 
   MGS_TRACE(TRACE_EVENTS - 3);
+  // This block has taken its last chunk records: count it now (the returned ticket is looked at after the final sum, so
+  // the atomic's round trip is hidden); whoever draws the last ticket reports the pool usage to the host.
+  uint32_t ticket = 0;
+  if (tid == 0) {
+    // (device-scope atomics served by the L2; the OR's returned value feeds the ticket, so it has been performed when the
+    //  ticket is counted -- no fence: a fence here costs every block ~3 us)
+    const uint32_t dep = overflow ? (atomicOr(&flags[FLAG_PREFILTERED], 0x100u) & 0u) : 0u;
+    ticket = atomicAdd(&flags[FLAG_BLOCKS_DONE], 1u + dep) + 1u;
+  }
   if (w == 0) { red_vis[lane] = 0; red_Tf[lane] = 1.0f; }
   __syncthreads();  // also: every wave's partial sums are written (workgroup scope)
   if (my_vis > 0) atomicMax(&red_vis[lane], my_vis);
@@ -382,11 +397,8 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     if (p.inside) final_T[p.pixa] = Tf;
     if (lane == 0) {
       nsurv[(size_t)tile * 4 + sub] = qtail;
-      // the last workgroup to finish reports {tag, overflow, chunk records used} to the host (mapped pinned memory)
-      // (all of these are device-scope atomics served by the L2; the returned value of the OR feeds the ticket, so the OR
-      //  has been performed when the ticket is counted -- no fence: a fence here costs every block ~3 us)
-      const uint32_t dep = overflow ? (atomicOr(&flags[FLAG_PREFILTERED], 0x100u) & 0u) : 0u;
-      if (atomicAdd(&flags[FLAG_BLOCKS_DONE], 1u + dep) + 1u == (uint32_t)nblocks && host_status) {
+      // the workgroup that drew the last ticket reports {tag, overflow, chunk records used} to the host (mapped pinned memory)
+      if (ticket == (uint32_t)nblocks && host_status) {
         const uint32_t used = __hip_atomic_load(&flags[FLAG_CHUNKS_USED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t ovf = (__hip_atomic_load(&flags[FLAG_PREFILTERED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) & 1u;
         __hip_atomic_store(host_status + 1, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)ovf << 32) | used,

@@ -31,7 +31,7 @@ def test_workspace_size_queries_and_options():
     assert L.mgs_geom_bytes(2000, 4, 128, 128) > L.mgs_geom_bytes(1000, 4, 128, 128)
     assert L.mgs_img_bytes(128, 128) >= 128 * 128 * 4
     assert L.mgs_binning_bytes2(5000, 64, 128, 128, 32) < L.mgs_binning_bytes(5000, 128, 128, 32)
-    assert L.mgs_chunk_pool_max(5000, 128, 128) == 4 * ((5000 + 63) // 64 + 64)
+    assert L.mgs_chunk_pool_max(5000, 128, 128) == 4 * ((5000 + 63) // 64 + 16 * 64)
     assert L.mgs_binning_bytes(5000, 128, 128, 32) > 5000 * 24
     assert L.mgs_binning_bytes(0, 128, 128, 0) > 0
     old = _lib.get_option("tight_bins")

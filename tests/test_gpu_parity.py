@@ -248,7 +248,7 @@ def test_async_forward_equals_blocking_forward_and_never_synchronises():
         _train_step(d, rast, dC, dF)
         mg.check_status(dev)
     R_mark, chunk_mark = st.marks[key]
-    assert chunk_mark is not None and 0 < chunk_mark < _lib.lib().mgs_chunk_pool_max(R_mark, W, W) // 2
+    assert chunk_mark is not None and 0 < chunk_mark <= _lib.lib().mgs_chunk_pool_max(R_mark, W, W) // 2
     # the asynchronous step: enqueue a long-running kernel first; the forward must return while it is still running
     spin = torch.empty(64 << 20, device=dev)
     ev = torch.cuda.Event()

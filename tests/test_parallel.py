@@ -113,3 +113,55 @@ def test_all_reduce_grads_aliasing_and_staging(tmp_path):
     expect[:4] = base[:4]                                  # the leading scratch region is outside the reduced span
     assert torch.equal(got["flat"], expect)
     assert torch.equal(got["c"], torch.full((3,), 3.0)) and torch.equal(got["d"], torch.full((2, 2), 3.0))
+
+
+# ---- bench.py --gpus N: the driver's command shape must launch N ranks by itself ------------------------------------------
+
+def _bench(args, timeout=600):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env={k: v for k, v in os.environ.items()
+                                             if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    return r, (json.loads(line) if line else None)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus 2` must never print an n_gpus = 1 line: without two HIP devices it exits with an error
+    (here: no device at all), and under a launcher it insists on WORLD_SIZE == --gpus."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the real launch is covered by the gpu test below")
+    r, j = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=300)
+    assert r.returncode != 0 and j is None
+    assert "HIP device" in (r.stderr + r.stdout)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_self_launches_two_ranks_on_one_device():
+    """The N > 1 path end to end where only one GPU exists: `bench.py --gpus 2` re-executes itself under
+    torch.distributed.run; --one-device --backend gloo are the testing flags (both ranks on cuda:0).  The JSON line must
+    say 2 ranks, name both devices, and carry the all-reduce volume (the parameter gradients only: 55 floats/Gaussian)."""
+    r, j = _bench(["--gpus", "2", "--one-device", "--backend", "gloo", "--steps", "20", "--warmup", "5", "--mode", "eager-st",
+                   "--only-mode", "--no-cpu-baseline", "--P", "20000"])
+    assert r.returncode == 0 and j is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    assert j["n_gpus"] == 2 and j["distributed"]["world_size_seen"] == 2 and len(j["distributed"]["device_ids"]) == 2
+    assert j["distributed"]["allreduce_bytes_per_step"] == 20000 * (3 + 1 + 12 + 3 + 4 + 32) * 4
+    assert j["distributed"]["allreduce_exposed_ms_per_step"] is not None and j["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_over_rccl():
+    """Two MI355X, RCCL: skipped on a one-GPU box (the driver's scaling run covers 1/2/4/8)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    r, j = _bench(["--gpus", "2", "--steps", "50", "--warmup", "10", "--no-cpu-baseline"])
+    assert r.returncode == 0 and j is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    assert j["n_gpus"] == 2 and j["distributed"]["backend"] == "nccl" and sorted(j["distributed"]["device_ids"]) == [0, 1]
