@@ -12,11 +12,14 @@ F=32, one look-at view per GPU per step, production negative-focal cameras, inpu
 + one backward of the rasterizer through the public GaussianRasterizer autograd API (+ one all-reduce of the per-Gaussian
 parameter gradients when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
 
-Modes (all three are timed; `value` comes from --mode, default graph):
-  graph     the step is captured once with torch.cuda.graph (the library's forward is asynchronous: no host
-            synchronisation inside) and replayed: what a training loop with a HIP-graphed render step runs;
-  eager     the same Python step called K times, torch's default autograd settings;
-  eager-st  eager with torch.autograd.set_multithreading_enabled(False) (round 1's headline setting).
+Modes (all three are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default eager-st):
+  eager-st  the Python step called K times with torch.autograd.set_multithreading_enabled(False): the backward is
+            enqueued by the calling thread.  The library never synchronises (asynchronous forward), so the host runs ahead
+            and the step is GPU-bound: ms_per_step == the sum of the kernel durations of rocprofv3 (profiles/).
+  eager     the same with torch's default autograd threading: every backward is handed to the engine's device thread and
+            back (two thread wake-ups per step, ~100 us of idle GPU at this step size).
+  graph     the step captured once with torch.cuda.graph and replayed (possible because nothing in the library
+            synchronises); one replay costs ~7 us more than the eagerly enqueued, already GPU-bound step.
 
 The JSON line also carries
   roofline      the dominant kernel (render backward) timed live with HIP events on its launch stream; what bounds it
@@ -60,7 +63,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st"])
+    ap.add_argument("--mode", default="eager-st", choices=["graph", "eager", "eager-st"])
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--F", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
@@ -415,19 +418,40 @@ def main():
         achieved = bytes_k8 / (bwd_avg_ms * 1e-3) / 1e9 if bwd_avg_ms > 0 else 0.0
         bytes_path = V * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)  # all V views
         so_hash = lib_hash()
-        cnt, why = committed_counters("gm_bwd_kernel", so_hash)
-        traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
-        roof = {"bound": "valu-issue", "kernel": "K8 render backward (gm_bwd_kernel)", "avg_launch_ms": bwd_avg_ms,
-                "launches": bwd_n,
-                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": bytes_k8, "traffic": traffic},
-                "traffic": traffic, "counters": cnt, "counters_note": why, "lib_sha256_16": so_hash}
-        if cnt and cnt.get("SQ_INSTS_VALU") and bwd_avg_ms > 0:
-            gips = cnt["SQ_INSTS_VALU"] / (bwd_avg_ms * 1e-3) / 1e9
-            roof.update({"achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s (VALU)",
-                         "frac": gips / VALU_PEAK_GIPS})
-        else:  # no counters for this binary: fall back to the HBM line (the kernel is NOT HBM-bound: see DESIGN.md)
-            roof.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
+        def roof_block(label, substr, avg_ms, launches, bytes_alg):
+            """What bounds a kernel, from the committed counter passes of THIS library (profiles/r02_sq_counters.json): no
+            throughput roof is near -- the waves spend their cycles waiting on dependent instructions and on memory / LDS /
+            barriers (SQ_WAIT_*).  The HBM line (algorithmic and counter bytes) is kept beside the issue numbers."""
+            cnt, why = committed_counters(substr, so_hash)
+            traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
+            ach = bytes_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            cycles = avg_ms * 1e-3 * 2.4e9  # upper bound: 2.4 GHz peak clock
+            rb = {"kernel": label, "avg_launch_ms": avg_ms, "launches": launches,
+                  "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": bytes_alg, "counter_bytes_per_launch": traffic,
+                          "frac_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None},
+                  "traffic": traffic, "counters_note": why, "lib_sha256_16": so_hash}
+            if cnt and cnt.get("SQ_INSTS_VALU") and cycles > 0:
+                gips = cnt["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
+                wc = cnt.get("SQ_WAVE_CYCLES") or 0.0
+                rb.update({
+                    "bound": "latency (dependent issue + waits; no throughput roof within 3x)",
+                    "achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s (VALU issue)", "frac": gips / VALU_PEAK_GIPS,
+                    "valu_busy_frac_of_simd_cycles": (cnt.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / (1024 * cycles),
+                    "mfma_busy_frac_of_simd_cycles": cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cycles),
+                    "wave_cycles_split": {k: (cnt[k] / wc if wc and k in cnt else None)
+                                          for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
+                    "per_launch": {k: cnt.get(k) for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA",
+                                                           "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD",
+                                                           "SQ_INSTS_VMEM_WR")}})
+            else:  # no counters for this binary: only the HBM line can be computed live (the kernels are NOT HBM-bound: DESIGN.md 4)
+                rb.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+            return rb
+
+        roof = roof_block("K8 render backward (gm_bwd_kernel)", "gm_bwd_kernel", bwd_avg_ms, bwd_n, bytes_k8)
+        bytes_k7 = R * (40 + 4 * F) + npix * (4 * (3 + F) + 8)  # SURVEY.md 8d, K7 rows
+        roof_fwd = roof_block("K7 render forward (coop_fwd_dense_kernel)", "coop_fwd_dense_kernel",
+                              stages.get("render_fwd", 0.0), min(steps, 20), bytes_k7)
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",
             "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
@@ -446,7 +470,7 @@ def main():
                             "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_ids": dev_ids,
                             "allreduce_bytes_per_step": ar_bytes,
                             "allreduce_exposed_ms_per_step": exposed_ms},
-            "roofline": roof,
+            "roofline": roof, "roofline_fwd": roof_fwd,
             "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path * NR,
                          "achieved_GBps": bytes_path * NR * n_gpus / (ms_step * 1e-3) / 1e9,
                          "frac_of_peak": bytes_path * NR / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -284,6 +284,8 @@ int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */
 int mgs_debug_read_trace(unsigned long long* host, size_t count);
+/* ... and of the render backward: 512 * 16 * 16 stamps (first chunk of every wave; scripts/trace_bwd.py). */
+int mgs_debug_read_trace_bwd(unsigned long long* host, size_t count);
 
 /* Device self-test of the wave64 cross-lane primitives used by the render kernels (DPP rotations,
  * v_permlane16/32_swap butterflies).  Returns 0 if every primitive matches its definition. */

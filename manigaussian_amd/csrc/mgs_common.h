@@ -13,7 +13,10 @@ constexpr int SUB = 8;           // execution granularity: one workgroup per 8x8
 constexpr int SUBS_PER_TILE = 4;
 constexpr int WAVE = 64;
 constexpr int CHUNK = 64;        // survivors per chunk of the render kernels (two 32-lane groups of the backward)
-constexpr int PRE_BLOCK = 1024;  // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
+#ifndef MGS_PRE_BLOCK
+#define MGS_PRE_BLOCK 1024
+#endif
+constexpr int PRE_BLOCK = MGS_PRE_BLOCK;  // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
 constexpr int LDS_TILES = 4096;  // max tiles whose per-tile tables fit the binning kernels' LDS (else: rocPRIM binning)
 constexpr int SEG_MIN = 512;     // smallest selectable sort segment (sizes the segment table)
 
@@ -95,7 +98,7 @@ struct ChunkView {
   float* partial;         // [pool][3+F][64]
   uint32_t* surv;         // [4][surv_stride]  block (tile, sub): surv[sub * surv_stride + ranges[tile].x + i] = instance id
   size_t surv_stride;     // = capacity of the instance list
-  uint32_t* nsurv;        // [T*4]  survivors found by the forward (a prefix of the block's full list)
+  uint2* nsurv;           // [T*4]  {survivors found by the forward (a prefix of the block's full list), first record of round 0}
 };
 
 size_t scan_temp_bytes(int P);
@@ -161,7 +164,7 @@ inline BinView carve_binning(void* p, int R, int T, int F, uint32_t pool, ChunkV
   const size_t items = v.pool;
   v.round_base = c.take<uint32_t>(round_table_entries(Ra, T));
   v.last_chunk = c.take<uint32_t>((size_t)T * 4 * 64);
-  v.nsurv = c.take<uint32_t>((size_t)T * 4);
+  v.nsurv = c.take<uint2>((size_t)T * 4);
   v.surv = c.take<uint32_t>(4 * Ra);
   v.surv_stride = Ra;
   v.T_end = c.take<float>(items * 64);

@@ -72,32 +72,50 @@ template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ float dpp_keep(float old, float v) {  // lanes without a source keep `old`
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
 }
-// inclusive prefix sum over the lanes of each 32-lane half (one v_add_f32_dpp per step, see the product scan below)
-#define MGS_SCAN_ADD_STEP(v, ctrl) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
+// Inclusive scans over the lanes of each 32-lane half, ONE asm block each (11 issue slots).  A DPP read needs two wait
+// states after a VALU write of its SOURCE register only, so the first three steps -- which all shift the unmodified input
+// %1 and fold it into the running value %0 (a plain operand: no hazard) -- issue back to back; after them lane i holds
+// x[i-3..i] (within its row of 16), and shifts by 4 and 8 and the row broadcast finish the 32 lanes.  Lanes whose DPP
+// source is out of range are not written (bound_ctrl off) and keep their value: exactly the scan's identity.  hipcc pads
+// nothing inside asm and nothing between these instructions (separate asm statements each got an extra s_nop from it).
 __device__ __forceinline__ float half_incl_scan_add(float v) {
-  MGS_SCAN_ADD_STEP(v, "row_shr:1 row_mask:0xf");
-  MGS_SCAN_ADD_STEP(v, "row_shr:2 row_mask:0xf");
-  MGS_SCAN_ADD_STEP(v, "row_shr:4 row_mask:0xf");
-  MGS_SCAN_ADD_STEP(v, "row_shr:8 row_mask:0xf");
-  MGS_SCAN_ADD_STEP(v, "row_bcast:15 row_mask:0xa");
-  return v;
+  float r = v;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+&v"(r) : "v"(v));
+  return r;
 }
-// exclusive prefix product over the lanes of each 32-lane half (lane 0 / 32 get 1)
-// The multiply steps are v_mul_f32_dpp with bound_ctrl:0: a lane whose DPP source is out of range is not written
-// and keeps its value -- exactly the scan's identity -- so a step is ONE instruction (the builtin route costs a
-// v_mov 1.0 + v_mov_dpp + v_mul per step).  hipcc pads nothing inside asm: the s_nop 1 covers the two wait states a
-// DPP read needs after the VALU write of its source.
-#define MGS_SCAN_MUL_STEP(v, ctrl) asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float half_incl_scan_mul(float v) {
+  float r = v;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+&v"(r) : "v"(v));
+  return r;
+}
+// exclusive prefix product over the lanes of each 32-lane half (lane 0 / 32 get 1): the input shifted by one lane, scanned
 __device__ __forceinline__ float half_excl_scan_mul(float v, int lane) {
   float s = dpp_keep<DPP_ROW_SHR1>(1.f, v);                       // lane i <- v[i-1] inside a row
   const float prev_row_last = dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, v);  // rows 1,3 <- v[15], v[47]
   s = ((lane & 15) == 0 && (lane & 16)) ? prev_row_last : s;
-  MGS_SCAN_MUL_STEP(s, "row_shr:1 row_mask:0xf");
-  MGS_SCAN_MUL_STEP(s, "row_shr:2 row_mask:0xf");
-  MGS_SCAN_MUL_STEP(s, "row_shr:4 row_mask:0xf");
-  MGS_SCAN_MUL_STEP(s, "row_shr:8 row_mask:0xf");
-  MGS_SCAN_MUL_STEP(s, "row_bcast:15 row_mask:0xa");
-  return s;
+  return half_incl_scan_mul(s);
 }
 // value of lane 31 (lanes 0..31) / lane 63 (lanes 32..63)
 __device__ __forceinline__ float half_last(float v, int lane) {

@@ -26,6 +26,15 @@ namespace mgs {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Phase timeline (diagnostic, MgsOptions.dbg = 256): s_memtime stamps per (workgroup, wave, event), first chunk of a wave only
+constexpr int BTRACE_EVENTS = 16;
+__device__ unsigned long long g_btrace[512 * 16 * BTRACE_EVENTS];
+#define MGS_BTRACE(ev)                                                                                     \
+  do {                                                                                                     \
+    if ((r.dbg & 256) && lane == 0 && blockIdx.x < 512 && w < 16)                                           \
+      g_btrace[((size_t)blockIdx.x * 16 + w) * BTRACE_EVENTS + (ev)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+
 template <int F>
 struct GmCfg {
   static constexpr int NCH = F + 3;                 // feature channels, then r, g, b
@@ -56,7 +65,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
                                                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeat,
                                                           const float* __restrict__ T_mid,
                                                           const uint32_t* __restrict__ surv, size_t surv_stride,
-                                                          const uint32_t* __restrict__ nsurv) {
+                                                          const uint2* __restrict__ nsurv) {
   using C = GmCfg<F>;
   constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
   constexpr int CH = CHUNK;
@@ -75,41 +84,75 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;
-  const uint32_t lc = last_chunk[((size_t)tile * 4 + sub) * 64 + lane];
-  const uint32_t lcmax = wave_umax(lc);
-  if (lcmax == 0) return;
+  MGS_BTRACE(0);
+  // The kernel is a chain of dependent memory round trips before the pixel loops start (measured: 36 k of a block's 132 k
+  // cycles, scripts/trace_bwd.py): everything that depends on the pixel alone is requested at once, up front.
   const PixBlk p = pix_blk(r, tile, sub, lane);
-  const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
   const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
   const size_t pix = p.pixl;
-  const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
-  const uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);
-  if (tid < (int)RBH && (uint32_t)tid * NWF < lcmax) rb_hist[tid] = my_rounds[4 * (size_t)tid];
-  __syncthreads();
-  auto slot_of = [&](uint32_t c) -> size_t {
-    const uint32_t rr = c / NWF;
-    return (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (size_t)(c % NWF);
-  };
-
-  // ---- pixel-lane prologue: dL of this block into LDS (both layouts), q[c] = dL . partial[c] ----
-  const float T_final = any ? final_T[p.pixa] : 0.f;
-  float bgT = 0.f;
-  {
-    float dLc[3] = {0.f, 0.f, 0.f};
-    float dLf[F > 0 ? F : 1];
+  const uint32_t lc = last_chunk[((size_t)tile * 4 + sub) * 64 + lane];
+  const uint2 rng = ranges[tile];
+  const uint2 nsv = nsurv[(size_t)tile * 4 + sub];  // {survivors the forward listed for this block, round 0's first record}
+  const uint32_t nsb = nsv.x;
+  float dLc[3] = {0.f, 0.f, 0.f};
+  float dLf[F > 0 ? F : 1];
 #pragma unroll
-    for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
-    if (any) {
+  for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
+  float T_final = 0.f;
+  if (p.inside) {
+    T_final = final_T[p.pixa];
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[((size_t)p.v * 3 + ch) * HW + pix];
-      if constexpr (F > 0) {
-        if (use_feat) {
+    for (int ch = 0; ch < 3; ch++) dLc[ch] = dL_dpix[((size_t)p.v * 3 + ch) * HW + pix];
+    if constexpr (F > 0) {
+      if (use_feat) {
 #pragma unroll
-          for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[((size_t)p.v * F + ch) * HW + pix];
-        }
+        for (int ch = 0; ch < F; ch++) dLf[ch] = dL_dpix_F[((size_t)p.v * F + ch) * HW + pix];
       }
     }
+  }
+  const uint32_t lcmax = wave_umax(lc);
+  if (lcmax == 0) return;
+  const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+  const uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);
+  // records of round 0 start at nsv.y (one load, no table, no barrier); later rounds (rare) go through the table in LDS
+  if (tid >= 1 && tid < (int)RBH && (uint32_t)tid * NWF < lcmax) rb_hist[tid] = my_rounds[4 * (size_t)tid];
+  if (tid == 0) rb_hist[0] = nsv.y;
+  auto slot_of = [&](uint32_t c) -> size_t {
+    const uint32_t rr = c / NWF;
+    return (size_t)(rr == 0 ? nsv.y : (rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr])) + (size_t)(c % NWF);
+  };
+  if (lcmax > NWF) __syncthreads();  // (workgroup-uniform) only blocks with a second round read the table
+  // ---- this wave's FIRST chunk (c = w): its per-pixel state and its survivors' records are requested now, so that they
+  //      arrive while q is being computed (they used to be three more round trips after the barrier) ----
+  const bool pf = (uint32_t)w < lcmax;
+  uint32_t pf_last = 0u, pf_id = 0u;
+  float pf_Tin = 1.0f, pf_Tmid = 1.0f;
+  float4 pf_g0 = make_float4(0, 0, 0, 0), pf_g1 = make_float4(0, 0, -1.f, -1.f);
+  if (pf) {
+    const size_t slot0 = slot_of((uint32_t)w);
+    if ((uint32_t)w < lc) pf_last = last_pos[slot0 * 64 + lane];
+    pf_Tmid = T_mid[slot0 * 64 + lane];
+    if (w > 0) pf_Tin = T_end[slot_of((uint32_t)w - 1u) * 64 + lane];
+    const uint32_t first = (uint32_t)w * (uint32_t)CH;
+    const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
+    if ((uint32_t)lane < nin) {
+      pf_id = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
+      pf_g0 = r.rec[2 * (size_t)pf_id]; pf_g1 = r.rec[2 * (size_t)pf_id + 1];
+    }
+  }
+
+  // ---- pixel-lane prologue: dL of this block into LDS (both layouts), q[c] = dL . partial[c] ----
+  if (!any) {
+    T_final = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dLc[ch] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
+  }
+  float bgT = 0.f;
+  float* qs = &trbuf[0][0];  // q of the block's first NW chunks, [chunk][pixel]: trbuf is idle until the first epilogue
+  {
     bgT = T_final * (r.bg[0] * dLc[0] + r.bg[1] * dLc[1] + r.bg[2] * dLc[2]);
     if (w == 0) {
       if constexpr (F > 0) {
@@ -123,6 +166,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
 #pragma unroll
       for (int ch = NCH; ch < KCH; ch++) dLT[ch][lane] = 0.f;
     }
+    MGS_BTRACE(1);
     for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
       const size_t slot = slot_of(c);
       float s = 0.f;
@@ -138,52 +182,78 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
         }
       }
       q[slot * 64 + lane] = s;
+      if (c < (uint32_t)NW) qs[c * 64 + (uint32_t)lane] = s;
     }
   }
-  __syncthreads();  // dLT/dLs (LDS) and q (global, this workgroup only) are visible to every wave
+  MGS_BTRACE(2);
+  __syncthreads();  // dLT/dLs, qs (LDS) and q (global, this workgroup only) are visible to every wave
+  MGS_BTRACE(3);
+  // what lies behind this wave's first chunk: dL . (the later chunks' partial colours), in chunk order; then the chunk is
+  // staged in this wave's LDS buffers right here, so that nothing prefetched stays live in registers across the loops
+  if (pf) {
+    const bool live0 = pf_last > 0u;
+    float pf_B = 0.f;
+    const uint32_t cl = min(lcmax, (uint32_t)NW);
+    for (uint32_t c2 = (uint32_t)w + 1u; c2 < cl; c2++) {
+      const float v = qs[c2 * 64 + (uint32_t)lane];
+      pf_B += (live0 && c2 < lc) ? v : 0.f;
+    }
+    for (uint32_t c2 = max((uint32_t)w + 1u, (uint32_t)NW); c2 < lcmax; c2++) {
+      const float v = q[slot_of(c2) * 64 + lane];
+      pf_B += (live0 && c2 < lc) ? v : 0.f;
+    }
+    pd[w][lane] = make_float4((live0 && w > 0) ? pf_Tin : 1.0f, live0 ? pf_B + bgT : 0.f, __uint_as_float(pf_last), pf_Tmid);
+    rec0[w][lane] = pf_g0; rec1[w][lane] = pf_g1; recid[w][lane] = make_uint2(pf_id, (uint32_t)lane + 1u);
+  }
+  __syncthreads();  // qs has been read: trbuf belongs to the epilogues again
 
   const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
   const int n = lane & 31, h = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
-  const uint32_t nsb = nsurv[(size_t)tile * 4 + sub];  // survivors the forward listed for this block
 
   for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
     // ---- pixel-lane: state of this chunk for my pixel ----
+    const bool first_it = c == (uint32_t)w;  // staged by the prologue
     const size_t slot = slot_of(c);
-    const uint32_t last = (c < lc) ? last_pos[slot * 64 + lane] : 0u;
+    if (first_it) wave_lds_sync();
+    const uint32_t last = first_it ? __float_as_uint(pd[w][lane].z) : ((c < lc) ? last_pos[slot * 64 + lane] : 0u);
     const uint32_t kmax = wave_umax(last);
     if (kmax == 0) continue;
     const bool live = last > 0;
     // pixels that blended something of group 0 / group 1 of this chunk: a pixel step whose two pixels (one per half-wave)
     // are both dead for the group contributes exact zeros to every sum and is skipped
     const unsigned long long lm0 = ballot(live), lm1 = ballot(last > 32u);
-    float B = 0.f;
-    for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
-      const float v = q[slot_of(c2) * 64 + lane];
-      B += (live && c2 < lc) ? v : 0.f;
-    }
-    const float T_in = (live && c > 0) ? T_end[slot_of(c - 1) * 64 + lane] : 1.0f;
-    // ---- entry-lane: the chunk's entries that reach this 8x8 block, compacted in order ----
+    if (first_it) MGS_BTRACE(4);
     int ns;
     {
       const uint32_t first = c * (uint32_t)CH;
       const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
       ns = (int)min(nin, kmax);
       if (ns == 0) continue;
-      float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
-      uint32_t id_e = 0;
-      if (lane < ns) {
-        id_e = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
-        g0 = r.rec[2 * (size_t)id_e]; g1 = r.rec[2 * (size_t)id_e + 1];
+      if (!first_it) {
+        float B = 0.f;
+        for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
+          const float v = q[slot_of(c2) * 64 + lane];
+          B += (live && c2 < lc) ? v : 0.f;
+        }
+        const float T_in = (live && c > 0) ? T_end[slot_of(c - 1) * 64 + lane] : 1.0f;
+        // ---- entry-lane: the chunk's survivors (the forward listed them in order) ----
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+        uint32_t id_e = 0;
+        if (lane < ns) {
+          id_e = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
+          g0 = r.rec[2 * (size_t)id_e]; g1 = r.rec[2 * (size_t)id_e + 1];
+        }
+        wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
+        pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
+        rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = make_uint2(id_e, (uint32_t)lane + 1u);
+        wave_lds_sync();
       }
-      wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
-      pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
-      rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = make_uint2(id_e, (uint32_t)lane + 1u);
-      wave_lds_sync();
     }
     const int ngroups = (ns + 31) >> 5;
 
     // ---- Gaussian-lane: groups of <= 32 entries, last group first (suffix sums run back to front) ----
+    if (c == (uint32_t)w) MGS_BTRACE(5);
     for (int g = ngroups - 1; g >= 0; --g) {
       const int gi = 32 * g + n;
       const bool has = gi < ns;
@@ -280,6 +350,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
       }
       if (g > 0) wave_lds_sync();  // pd[].y updates visible before the next group reads them
 
+      if (c == (uint32_t)w) MGS_BTRACE(g == 0 ? 8 : 6);
       // ---- hand the group's sums to memory: transpose through LDS so that every atomic instruction covers whole
       //      rows (32 consecutive feature channels of one Gaussian = one 128-B line; 8 Gaussians x 6 geometry sums;
       //      16 Gaussians x 3 colour sums) instead of 64 different lines ----
@@ -327,9 +398,11 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
                             tr[gg * TROW + NCT * 32 + 6 + i]);
         }
         wave_lds_sync();  // tr / gid are rewritten by the next group
+        if (c == (uint32_t)w) MGS_BTRACE(g == 0 ? 9 : 7);
       }
     }
   }
+  MGS_BTRACE(15);
 }
 
 // ------------------------------------------- dispatch ------------------------------------------------
@@ -371,3 +444,9 @@ hipError_t launch_render_bwd_gm(const RenderArgs& r, const BinView& b, const Img
 }
 
 }  // namespace mgs
+
+// diagnostic: copy the backward's phase timeline out (count = 512 * 16 * 16 uint64)
+extern "C" int mgs_debug_read_trace_bwd(unsigned long long* host, size_t count) {
+  const size_t n = sizeof(mgs::g_btrace) / sizeof(unsigned long long);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mgs::g_btrace), (count < n ? count : n) * sizeof(unsigned long long));
+}

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(NW * 64)
 coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       float* __restrict__ T_end, float* __restrict__ T_mid,
                       uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
-                      size_t surv_stride, uint32_t* __restrict__ nsurv, float* __restrict__ final_T,
+                      size_t surv_stride, uint2* __restrict__ nsurv, float* __restrict__ final_T,
                       uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat,
                       uint32_t* __restrict__ round_base, uint32_t pool, uint32_t* __restrict__ flags, int nblocks,
                       uint64_t* host_status, uint32_t status_tag) {
@@ -57,7 +57,8 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   constexpr int NOWN = (NCH + NW - 1) / NW;  // image channels owned by one wave
   constexpr uint32_t ROUND = NW * CHS;       // survivors blended per round
   constexpr uint32_t FSTEP = NW * 64;        // entries examined per fill sub-step (one per thread)
-  constexpr int FILLK = 2;                   // sub-steps per fill step (all loads in flight together)
+  constexpr int FILLK = 3;                   // sub-steps per fill step (all loads in flight together): at BASELINE configs[2]
+                                             // a block needs ~2400 list entries for its first 1024 survivors -- one step, not two
   __shared__ float trs[MF ? NW * NT * 32 * TRS : 1];  // per wave: [channel][pixel] hand-over of the MFMA accumulators
   __shared__ float Tp[2][NW][64];            // per-chunk transmittance products, double buffered over rounds
   __shared__ float red_Tf[64];
@@ -363,10 +364,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
   for (int k = 0; k < NOWN; k++) img[k] = 0.f;
   const uint32_t vmax = wave_umax(vis);
-  for (uint32_t c0 = 0; c0 < vmax; c0 += 4) {  // four records' loads in flight; the sum stays in chunk order
-    float v[4][NOWN];
+  constexpr int NFLY = 8;  // records whose loads are in flight together (a block visits ~7 chunks at BASELINE configs[2])
+  for (uint32_t c0 = 0; c0 < vmax; c0 += NFLY) {  // the sum stays in chunk order
+    float v[NFLY][NOWN];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NFLY; u++) {
       const uint32_t cc = c0 + u;
       const uint32_t rr = cc / NW;
       const size_t slot = cc < vis ? (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (cc % NW) : 0;
@@ -374,11 +376,11 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
       for (int k = 0; k < NOWN; k++) {
         const int ch = w + k * NW;
-        v[u][k] = (c0 + u < vis && ch < NCH && (ch < 3 || use_feat)) ? pp[ch * 64] : 0.f;
+        v[u][k] = (cc < vis && ch < NCH && (ch < 3 || use_feat)) ? pp[ch * 64] : 0.f;
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < NFLY; u++)
 #pragma unroll
       for (int k = 0; k < NOWN; k++) img[k] += v[u][k];
   }
@@ -396,7 +398,7 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     last_chunk[((size_t)tile * 4 + sub) * 64 + lane] = vis;
     if (p.inside) final_T[p.pixa] = Tf;
     if (lane == 0) {
-      nsurv[(size_t)tile * 4 + sub] = qtail;
+      nsurv[(size_t)tile * 4 + sub] = make_uint2(qtail, round > 0 || vis > 0 ? rb_hist[0] : 0u);  // + round 0's first record
       // the workgroup that drew the last ticket reports {tag, overflow, chunk records used} to the host (mapped pinned memory)
       if (ticket == (uint32_t)nblocks && host_status) {
         const uint32_t used = __hip_atomic_load(&flags[FLAG_CHUNKS_USED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

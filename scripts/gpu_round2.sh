@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 want() { for a in "$@"; do [ "$a" = "$W" ] && return 0; done; return 1; }
-for W in tests graph skips bisect noscratch scratch dump oob host bench stats pmc configs; do
+for W in tests graph trace variants skips bisect noscratch scratch dump oob host bench stats pmc configs; do
   want "$@" || continue
   case $W in
   tests)
@@ -15,6 +15,21 @@ for W in tests graph skips bisect noscratch scratch dump oob host bench stats pm
     for PP in 20000 100000; do timeout 120 python tests/tools/graph_capture_check.py $PP > $OUT/graph_check_$PP.log 2>&1; echo "graph check P=$PP rc=$?"; grep -v "^  File\|^$" $OUT/graph_check_$PP.log | head -12; done ;;
   graph)
     for PP in 20000; do timeout 120 python tests/tools/graph_capture_check.py $PP > $OUT/graph_check_$PP.log 2>&1; echo "graph check P=$PP rc=$?"; grep -v "^  File\|^$" $OUT/graph_check_$PP.log | head -12; done ;;
+  trace)
+    timeout 200 python scripts/trace_fwd.py > $OUT/trace_fwd.log 2>&1; echo "trace rc=$?"; cat $OUT/trace_fwd.log | tail -22
+    timeout 200 python scripts/trace_bwd.py > $OUT/trace_bwd.log 2>&1; echo "trace bwd rc=$?"; cat $OUT/trace_bwd.log | tail -22 ;;
+  variants)
+    # experimental builds manigaussian_amd/libmgsplat_<tag>.so swapped in one at a time: kernel stats of a short bench
+    cp manigaussian_amd/libmgsplat.so /tmp/libmgsplat_keep.so
+    for so in manigaussian_amd/libmgsplat_*.so; do
+      tag=$(basename $so .so); tag=${tag#libmgsplat_}
+      cp $so manigaussian_amd/libmgsplat.so
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/var_$tag -o stats -- python bench.py --mode eager-st --only-mode --steps 200 --warmup 30 --no-cpu-baseline > $OUT/var_$tag.log 2>&1
+      echo "variant $tag: $(tail -1 $OUT/var_$tag.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['ms_per_step'],4))")"
+      python scripts/top_kernels.py $OUT/var_$tag | head -10
+      find $OUT/var_$tag -name "*kernel_trace.csv" -delete
+    done
+    cp /tmp/libmgsplat_keep.so manigaussian_amd/libmgsplat.so ;;
   skips)
     for sk in status images grads status,images,grads; do
       MGS_GRAPH_SKIP=$sk timeout 100 python tests/tools/graph_capture_check.py 20000 > $OUT/skip_$sk.log 2>&1; echo "skip $sk rc=$? $(grep -c GRAPH_OK $OUT/skip_$sk.log) $(grep -c fault $OUT/skip_$sk.log) last: $(grep stage $OUT/skip_$sk.log | tail -1)"

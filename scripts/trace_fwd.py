@@ -41,7 +41,7 @@ rel = np.where(t > 0, t - t0[:, None, None], -1)
 names = {0: "entry", 1: "fill done r0", 2: "list barrier r0", 3: "rows staged r0", 4: "phase A done r0", 5: "Tp barrier r0",
          6: "phase B done r0", 7: "round end r0", 9: "fill done r1", 10: "list barrier r1", 11: "rows r1", 12: "phase A r1",
          13: "Tp barrier r1", 14: "phase B r1", 15: "round end r1", 21: "before final", 22: "image summed", 23: "exit"}
-print(f"variant {variant}; shader-clock cycles (s_memtime) since the block's first stamp; per block the LAST wave counts")
+print(f"shader-clock cycles (s_memtime) since the block's first stamp; per block the LAST wave counts")
 for e, n in names.items():
     v = rel[:, :, e].max(1)           # the slowest wave of each block reaches the event
     m = v >= 0
