@@ -92,8 +92,14 @@ class ForwardHandle:
 
     def __int__(self):
         if self.R < 0 and self.pending is not None:
+            spins = 0
             while self.pending.num_rendered < 0 and self.pending.poll() == _lib.MGS_PENDING:
-                pass
+                spins += 1
+                if spins == 100000:  # ~0.1 s of polling: let the stream finish; a count that is still missing never comes
+                    torch.cuda.synchronize()
+                    if self.pending.num_rendered < 0 and self.pending.poll() == _lib.MGS_PENDING and \
+                            self.pending.num_rendered < 0:
+                        raise RuntimeError("the rasterizer forward finished without reporting its instance count")
             self.R = self.pending.num_rendered
         return self.R
 

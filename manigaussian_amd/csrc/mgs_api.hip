@@ -302,6 +302,7 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
   r.W = a->W; r.H = a->H; r.tiles_x = (a->W + TILE - 1) / TILE; r.tiles_y = (a->H + TILE - 1) / TILE;
   r.F = F; r.include_feature = F > 0;
   r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg;
+  r.nwf = fwd_waves(F, r.tiles_x * r.tiles_y);
   r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
   r.bg = a->background;
   r.colors = a->colors_precomp ? a->colors_precomp : g.rgb;
@@ -604,6 +605,7 @@ static RenderArgs views_render_args(const MgsRasterArgs* a, const Options& o, co
   const int F = a->include_feature ? a->F : 0;
   r.W = a->W; r.H = at.H; r.tiles_x = at.tiles_x; r.tiles_y = at.tiles_yv * at.V; r.F = F; r.include_feature = F > 0;
   r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = 0;
+  r.nwf = fwd_waves(F, r.tiles_x * r.tiles_y);
   r.V = at.V; r.Pg = a->P; r.Hv = a->H; r.Hp = at.Hp;
   r.colors_per_view = a->colors_precomp ? 0 : 1;
   r.bg = a->background;

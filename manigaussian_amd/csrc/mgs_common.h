@@ -253,8 +253,15 @@ hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im,
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj,
                                uint8_t* present, hipStream_t s);
 
+// Waves (= chunks per round) of the render forward, RenderArgs::nwf: 16 waves x 128 registers fill a CU with ONE workgroup;
+// wide rows (F = 64) need 256 registers (8 waves).  When the grid has more blocks than the chip has CUs (multi-view
+// batches, images above 128 x 128), 8-wave workgroups are used as well, TWO per CU (<= 80 KB of LDS, 128 registers): a CU then
+// interleaves the latency chains of two pixel blocks instead of idling on one.
+inline int fwd_waves(int F, int tiles) { return (F > 32 || 4 * tiles > 256) ? 8 : 16; }
+
 struct RenderArgs {
   int W, H, tiles_x, tiles_y, F, include_feature, fast_exp, exact_cull, gm_waves;
+  int nwf;  // waves of the render forward = chunk records per round (fwd_waves(): a function of F and the tile count)
   // Multi-view batches render into an ATLAS: V views stacked vertically, each padded to Hp = tiles_y_view * 16 rows, so
   // that binning and compositing see one image of H = V * Hp rows (V == 1: H is the image height, Hv == H).
   // Instance ids are then "virtual": id = view * Pg + Gaussian.

@@ -51,9 +51,10 @@ struct GmRec { float4 g0, g1; uint32_t id, pos; };
 
 // A chunk is 64 consecutive SURVIVORS of this block's compacted list `surv` (written by the forward: no culling here,
 // groups are full) and T_mid is the transmittance entering the second group.  Chunk c's record is
-// round_base[round c / NWF] + c % NWF with NWF = the forward's waves (FwdWaves<F>).
-template <int F, bool FAST, int NW>
-__global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uint2* __restrict__ ranges,
+// round_base[round c / NWF] + c % NWF with NWF = the forward's waves (RenderArgs::nwf).
+// NWF: waves of the forward that wrote the state (chunk records per round).  TWO: two workgroups share a CU.
+template <int F, bool FAST, int NW, int NWF_, bool TWO>
+__global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs r, const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ round_base,
                                                           const uint32_t* __restrict__ last_chunk,
                                                           const float* __restrict__ T_end,
@@ -69,14 +70,14 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
   using C = GmCfg<F>;
   constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
   constexpr int CH = CHUNK;
-  constexpr uint32_t NWF = FwdWaves<F>::value;
-  constexpr uint32_t RBH = 32;            // rounds whose first record is staged in LDS
+  constexpr uint32_t NWF = NWF_;
+  constexpr uint32_t RBH = 8;             // rounds whose first record is staged in LDS
   __shared__ uint32_t rb_hist[RBH];
-  __shared__ float dLT[KCH][64];          // [channel][pixel]: A operand of the D contraction
-  __shared__ float dLs[64 * SROW];        // [pixel][feature channel, zero padded]: A operand of the feature contraction
+  __shared__ float dLT[KCH][65];          // [channel][pixel] (odd stride): A operand of the D contraction, read by rows, and
+                                          // of the feature contraction, read by columns (lane = channel)
   __shared__ float4 pd[NW][64];           // per wave, per pixel: {T_in, S_after + T_final*bg.dL, last (bits), T_in of group 1}
   __shared__ float4 rec0[NW][64], rec1[NW][64];  // per wave: compacted entries of the current chunk (packed records)
-  __shared__ uint2 recid[NW][64];                // ... {Gaussian id, 1-based position in the chunk}
+  __shared__ uint32_t recid[NW][64];             // ... their instance ids (entry e of the chunk sits at index e)
   constexpr int TROW = NCT * 32 + 9;      // per wave: [32 Gaussians][feature sums | 9 scalar sums], odd stride
   __shared__ float trbuf[NW][32 * TROW];
   __shared__ uint2 gid[NW][32];           // per wave: {instance id, Gaussian} of the group's lanes (0xffffffff: empty lane)
@@ -157,9 +158,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
     if (w == 0) {
       if constexpr (F > 0) {
 #pragma unroll
-        for (int ch = 0; ch < F; ch++) { dLT[ch][lane] = dLf[ch]; dLs[lane * SROW + ch] = dLf[ch]; }
-#pragma unroll
-        for (int ch = F; ch < NCT * 32; ch++) dLs[lane * SROW + ch] = 0.f;
+        for (int ch = 0; ch < F; ch++) dLT[ch][lane] = dLf[ch];
       }
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) dLT[F + ch][lane] = dLc[ch];
@@ -203,7 +202,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
       pf_B += (live0 && c2 < lc) ? v : 0.f;
     }
     pd[w][lane] = make_float4((live0 && w > 0) ? pf_Tin : 1.0f, live0 ? pf_B + bgT : 0.f, __uint_as_float(pf_last), pf_Tmid);
-    rec0[w][lane] = pf_g0; rec1[w][lane] = pf_g1; recid[w][lane] = make_uint2(pf_id, (uint32_t)lane + 1u);
+    rec0[w][lane] = pf_g0; rec1[w][lane] = pf_g1; recid[w][lane] = pf_id;
   }
   __syncthreads();  // qs has been read: trbuf belongs to the epilogues again
 
@@ -246,7 +245,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
         }
         wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
         pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
-        rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = make_uint2(id_e, (uint32_t)lane + 1u);
+        rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = id_e;
         wave_lds_sync();
       }
     }
@@ -260,8 +259,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
       GmRec rec;
       {
         const int ri = has ? gi : 0;
-        const uint2 re = recid[w][ri];
-        rec.g0 = rec0[w][ri]; rec.g1 = rec1[w][ri]; rec.id = re.x; rec.pos = re.y;
+        rec.g0 = rec0[w][ri]; rec.g1 = rec1[w][ri]; rec.id = recid[w][ri]; rec.pos = (uint32_t)ri + 1u;  // 1-based position
       }
       const float ex = rec.g0.x, ey = rec.g0.y, cx = rec.g0.z, cy = rec.g0.w, cz = rec.g1.x;
       const float op = has ? rec.g1.y : 0.f;
@@ -341,7 +339,7 @@ __global__ void __launch_bounds__(NW * 64) gm_bwd_kernel(RenderArgs r, const uin
             if (use_feat) {
 #pragma unroll
               for (int ct = 0; ct < NCT; ct++) {
-                const float a = dLs[pp * SROW + 32 * ct + n];        // A[i = channel 32ct+n][k = h]: my pixel's dL
+                const float a = (32 * ct + n < KCH) ? dLT[32 * ct + n][pp] : 0.f;  // A[i = channel 32ct+n][k = h]: my pixel's dL
                 Cf[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa, Cf[ct], 0, 0, 0);  // B[k = h][j = n] = wa
               }
             }
@@ -411,21 +409,21 @@ static hipError_t gm_F(const RenderArgs& r, const ImgView& im, const ChunkView& 
                        float* acc8, float* dcol, float* dfeat, hipStream_t s) {
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_GM(FAST, NW)                                                                                              \
-  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, NW>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges, cv.round_base,       \
-                     cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, acc8, dcol, dfeat,   \
-                     cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
-  // 8 waves per workgroup: 256 registers per lane (no spills); 16 waves: more latency hiding, 128 registers
-  bool launched = false;
-  if constexpr (F <= 32) {
-    if (r.gm_waves != 8) {
-      if (r.fast_exp) MGS_GM(true, 16); else MGS_GM(false, 16);
-      launched = true;
-    }
+#define MGS_GM(FAST, NW, NWF, TWO)                                                                                    \
+  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, NW, NWF, TWO>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges,            \
+                     cv.round_base, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, acc8, \
+                     dcol, dfeat, cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
+#define MGS_GMF(NW, NWF, TWO) do { if (r.fast_exp) MGS_GM(true, NW, NWF, TWO); else MGS_GM(false, NW, NWF, TWO); } while (0)
+  if constexpr (F > 32) {
+    MGS_GMF(8, 8, false);                        // wide rows: 8 waves x 256 registers (the forward ran 8 waves as well)
+  } else if (r.nwf == 8) {
+    MGS_GMF(8, 8, true);                         // more blocks than CUs: two 8-wave workgroups per CU
+  } else if (r.gm_waves == 8) {
+    MGS_GMF(8, 16, false);                       // option: 8 waves x 256 registers behind a 16-wave forward
+  } else {
+    MGS_GMF(16, 16, false);
   }
-  if (!launched) {
-    if (r.fast_exp) MGS_GM(true, 8); else MGS_GM(false, 8);
-  }
+#undef MGS_GMF
 #undef MGS_GM
   return hipGetLastError();
 }

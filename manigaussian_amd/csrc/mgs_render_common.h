@@ -110,14 +110,6 @@ constexpr uint32_t ROUND_GRANULE = 512;
 __device__ __forceinline__ size_t round_entry(uint32_t range_x, int tile, int sub, uint32_t r) {
   return ((size_t)(range_x / ROUND_GRANULE) + 2 * (size_t)tile + r) * 4 + (size_t)sub;
 }
-// waves (= chunks per round) of the render forward for feature width F: 16 waves x 128 registers fill a CU; wide rows
-// (F = 64) need 256 registers
-#ifdef MGS_FWD_WAVES8  // experiment: 8 waves x 256 registers (no scratch) for every feature width
-template <int F> struct FwdWaves { static constexpr int value = 8; };
-#else
-template <int F> struct FwdWaves { static constexpr int value = F <= 32 ? 16 : 8; };
-#endif
-
 // Feature widths compiled in.  Other widths are padded up by the host shim (zero channels change nothing).
 #define MGS_FOR_EACH_F(X) X(0) X(3) X(4) X(8) X(16) X(32) X(64)
 

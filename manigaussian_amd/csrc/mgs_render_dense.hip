@@ -37,8 +37,9 @@ __device__ unsigned long long g_trace[512 * 16 * TRACE_EVENTS];
 //     transposition per chunk.
 //   * the three colour channels (and every channel when F < 16) are FMAs against v_readlane broadcasts of the row
 //     registers of the lane that owns the entry.
-template <int F, bool FAST, bool EXACT, int NW, int CHS>
-__global__ void __launch_bounds__(NW * 64)
+// TWO: two workgroups of this kernel share a CU (8 waves, <= 128 registers, <= 80 KB of LDS each)
+template <int F, bool FAST, bool EXACT, int NW, int CHS, bool TWO>
+__global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1)
 coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       float* __restrict__ T_end, float* __restrict__ T_mid,
                       uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
@@ -415,17 +416,23 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 template <int F>
 static hipError_t dense_F(const RenderArgs& r, const BinView& b, const ImgView& im, const ChunkView& cv, float* oc,
                           float* of, StatusSink st, hipStream_t s) {
-  constexpr int NW = FwdWaves<F>::value;
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_CFD(FAST, EXACT)                                                                                          \
-  hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHUNK>), dim3(grid), dim3(NW * 64), 0, s, r,           \
+#define MGS_CFD_(FAST, EXACT, NW, TWO)                                                                                \
+  hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHUNK, TWO>), dim3(grid), dim3(NW * 64), 0, s, r,      \
                      im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
                      cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of, cv.round_base, cv.pool, im.flags,   \
                      4 * T, st.host, st.tag)
+#define MGS_CFD(FAST, EXACT)                                                                                          \
+  do {                                                                                                                \
+    if constexpr (F > 32) MGS_CFD_(FAST, EXACT, 8, false);          /* 256 registers per lane */                     \
+    else if (r.nwf == 8) MGS_CFD_(FAST, EXACT, 8, true);            /* two workgroups per CU */                        \
+    else MGS_CFD_(FAST, EXACT, 16, false);                                                                            \
+  } while (0)
   if (r.fast_exp) { if (r.exact_cull) MGS_CFD(true, true); else MGS_CFD(true, false); }
   else            { if (r.exact_cull) MGS_CFD(false, true); else MGS_CFD(false, false); }
 #undef MGS_CFD
+#undef MGS_CFD_
   return hipGetLastError();
 }
 

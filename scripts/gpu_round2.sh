@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 want() { for a in "$@"; do [ "$a" = "$W" ] && return 0; done; return 1; }
-for W in tests graph trace variants skips bisect noscratch scratch dump oob host bench stats pmc configs; do
+for W in tests graph trace multi variants skips bisect noscratch scratch dump oob host bench stats pmc configs; do
   want "$@" || continue
   case $W in
   tests)
@@ -58,6 +58,11 @@ for W in tests graph trace variants skips bisect noscratch scratch dump oob host
   bench)
     timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"
     tail -1 $OUT/bench.log | cut -c1-3000 ;;
+  multi)
+    for c in "--config c5shape" "--views 8" "--views 4" "--config c2 --size 256"; do
+      timeout 600 python bench.py $c --no-cpu-baseline --only-mode > $OUT/bench_multi.log 2>&1; echo "bench $c rc=$?"
+      tail -1 $OUT/bench_multi.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); c=j['config']; print(c['name'], c['P'], c['W'], 'V', c['views_per_gpu'], round(j['ms_per_step'],4), 'ms/step', round(j['ms_per_step']/c['renders_per_step_per_gpu'],4), 'ms/render', round(j['value']/1e6,1), 'M/s', {k: round(v,4) for k,v in j['stages_ms'].items() if v})"
+    done ;;
   configs)
     for c in c2 c5shape ref16k c4; do
       timeout 900 python bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.log 2>&1; echo "bench $c rc=$?"
