@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 want() { for a in "$@"; do [ "$a" = "$W" ] && return 0; done; return 1; }
-for W in tests graph trace multi variants skips bisect noscratch scratch dump oob host bench stats pmc configs; do
+for W in tests graph trace stats5 multi variants skips bisect noscratch scratch dump oob host bench stats pmc configs; do
   want "$@" || continue
   case $W in
   tests)
@@ -58,6 +58,11 @@ for W in tests graph trace multi variants skips bisect noscratch scratch dump oo
   bench)
     timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"
     tail -1 $OUT/bench.log | cut -c1-3000 ;;
+  stats5)
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python bench.py --config c5shape --only-mode --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_rocprof_c5.log 2>&1
+    python scripts/top_kernels.py $OUT/stats_c5; find $OUT/stats_c5 -name "*kernel_trace.csv" -delete
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_v8 -o stats -- python bench.py --views 8 --only-mode --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_rocprof_v8.log 2>&1
+    python scripts/top_kernels.py $OUT/stats_v8; find $OUT/stats_v8 -name "*kernel_trace.csv" -delete ;;
   multi)
     for c in "--config c5shape" "--views 8" "--views 4" "--config c2 --size 256"; do
       timeout 600 python bench.py $c --no-cpu-baseline --only-mode > $OUT/bench_multi.log 2>&1; echo "bench $c rc=$?"
