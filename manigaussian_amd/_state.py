@@ -44,6 +44,22 @@ def forward_mode() -> str:
     return _MODE
 
 
+# Head-room of an asynchronous forward's workspace over the high-water marks of its shape: the scene may grow by these
+# factors from one call to the next before a call overflows (and raises, late).  Scenes that differ wildly between calls of
+# one shape (a parity sweep, a data loader mixing scenes) want more, or set_forward_mode("blocking").
+_HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.25)),
+             "chunks": float(os.environ.get("MGS_HEADROOM_CHUNKS", 1.5))}
+
+
+def set_headroom(instances: float = None, chunks: float = None):
+    """Factors (>= 1) by which an asynchronous forward's instance list / chunk-record pool exceed the largest count seen."""
+    for k, v in (("instances", instances), ("chunks", chunks)):
+        if v is not None:
+            if not v >= 1.0:
+                raise ValueError("head-room factors are >= 1")
+            _HEADROOM[k] = float(v)
+
+
 class Pending:
     """One forward whose device report has not been read yet."""
     __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured")
@@ -107,7 +123,7 @@ class DeviceState:
         m = self.marks.get(key)
         if m is None or m[1] is None:
             return None
-        return m[0] + m[0] // 4 + 4096, m[1] + m[1] // 2 + 64
+        return int(m[0] * _HEADROOM["instances"]) + 4096, int(m[1] * _HEADROOM["chunks"]) + 64
 
     def learn(self, key, R=None, chunks=None, pool_unknown=False):
         m = self.marks.setdefault(key, [0, None])

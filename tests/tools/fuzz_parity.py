@@ -12,6 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import util  # noqa: E402
+import manigaussian_amd  # noqa: E402
+
+manigaussian_amd.set_forward_mode("blocking")  # every case is another scene of a recurring shape: no workspace guessing
 
 IMG_TOL, GRAD_TOL = 1e-4, 1e-3
 
