@@ -238,6 +238,17 @@ int mgs_deform_apply_forward(int N, const float* xyz, const float* rot, const fl
 int mgs_deform_apply_backward(int N, const float* rot, const float* delta, const float* g_xyz_out,
                               const float* g_rot_out, float* g_delta, mgs_stream_t stream);
 
+/* ---- deformation field MLP: the elementwise passes between the GEMMs of ResnetFC, fused -----------------------------------
+ * (MG/.../resnetfc.py:10-62: ResnetBlockFC  x + fc_1(relu(fc_0(relu(x)))),  :65-177 ResnetFC).  The GEMMs stay with the
+ * caller's BLAS; x, act, g_* are row-major [M, N] fp32, N a multiple of 4 with N/4 dividing 256.
+ * forward:  relu_out = max(x, 0);  xb_out = x + bias[N]   (either output, and bias, may be NULL) */
+int mgs_mlp_relu_bias(int M, int N, const float* x, const float* bias, float* relu_out, float* xb_out,
+                      mgs_stream_t stream);
+/* backward: g_out = g_pre * (act > 0) [+ g_res];  colsum[n] += sum_m g_out[m][n]  (the bias gradient; NULL: not wanted;
+ * the caller zeroes it).  g_out may alias g_pre or g_res. */
+int mgs_mlp_relu_backward(int M, int N, const float* g_pre, const float* act, const float* g_res, float* g_out,
+                          float* colsum, mgs_stream_t stream);
+
 /* ---- Gaussian-regressor epilogue (MG/models_embed.py:233-253, MG/gaussian_renderer/__init__.py:66-68) ----
  * raw [N,26] = xyz 3 | opacity 1 | scale 3 | rot 4 | f_dc 3 | feature 3 | f_rest 9 (the split of models_embed.py:121,139-141)
  *   xyz = xyz_in + raw.xyz;  opacity = sigmoid;  scale = min(exp, 0.05);  rot = normalize (eps 1e-12);

@@ -91,6 +91,8 @@ _EXPORTS = {
     "mgs_deform_assemble_backward": (ctypes.c_int, [ctypes.c_int] * 5 + [c_fp] * 3 + [c_fp]),
     "mgs_deform_apply_forward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 5 + [c_fp]),
     "mgs_deform_apply_backward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 5 + [c_fp]),
+    "mgs_mlp_relu_bias": (ctypes.c_int, [ctypes.c_int] * 2 + [c_fp] * 4 + [c_fp]),
+    "mgs_mlp_relu_backward": (ctypes.c_int, [ctypes.c_int] * 2 + [c_fp] * 5 + [c_fp]),
     "mgs_regress_epilogue_forward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 9 + [c_fp]),
     "mgs_regress_epilogue_backward": (ctypes.c_int, [ctypes.c_int] + [c_fp] * 9 + [c_fp]),
     "mgs_voxel_sample_pe_forward": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float)] +

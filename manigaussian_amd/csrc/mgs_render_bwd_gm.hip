@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
                                                           const uint32_t* __restrict__ surv, size_t surv_stride,
                                                           const uint2* __restrict__ nsurv) {
   using C = GmCfg<F>;
-  constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT, SROW = C::SROW;
+  constexpr int NCH = C::NCH, KCH = C::KCH, NCT = C::NCT;
   constexpr int CH = CHUNK;
   constexpr uint32_t NWF = NWF_;
   constexpr uint32_t RBH = 8;             // rounds whose first record is staged in LDS

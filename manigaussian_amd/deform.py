@@ -130,9 +130,144 @@ class ResnetBlockFC(nn.Module):
         return x + self.fc_1(torch.relu(self.fc_0(torch.relu(x))))
 
 
+# ---- the same network with the elementwise passes fused (mgs_mlp.hip) and the GEMMs issued by hand ------------------
+
+def _mlp_ok(n):
+    return n % 4 == 0 and (n // 4) <= 256 and 256 % (n // 4) == 0
+
+
+def _relu_bias(x, bias, want_relu=True, want_xb=True):
+    """(relu(x), x + bias) in one pass over x."""
+    M, N = x.shape
+    a = torch.empty_like(x) if want_relu else None
+    xb = torch.empty_like(x) if want_xb else None
+    _lib.check(_lib.lib().mgs_mlp_relu_bias(M, N, x.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                            0 if a is None else a.data_ptr(), 0 if xb is None else xb.data_ptr(),
+                                            _stream(x.device)), "mgs_mlp_relu_bias")
+    return a, xb
+
+
+def _relu_backward(g_pre, act, g_res, colsum):
+    """g_pre * (act > 0) [+ g_res] written over g_pre; colsum (zeroed [N]) accumulates the column sums of the result."""
+    M, N = g_pre.shape
+    _lib.check(_lib.lib().mgs_mlp_relu_backward(M, N, g_pre.data_ptr(), act.data_ptr(),
+                                                0 if g_res is None else g_res.data_ptr(), g_pre.data_ptr(),
+                                                0 if colsum is None else colsum.data_ptr(), _stream(g_pre.device)),
+               "mgs_mlp_relu_backward")
+    return g_pre
+
+
+_WGRAD_SPLIT = 8        # batches of the split-K weight gradient
+_WGRAD_MIN_ROWS = 4096  # ... taken when each batch still has this many rows
+
+
+def _wgrad(g, x):
+    """g^T @ x ([M, No], [M, K] -> [No, K]).  The output is small and the reduction long (M rows): split the rows into
+    batches so that the GEMM fills the chip, then add the partial products."""
+    M = g.shape[0]
+    S = _WGRAD_SPLIT
+    if S > 1 and M % S == 0 and M >= _WGRAD_MIN_ROWS * S:
+        return torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0)
+    return g.t() @ x
+
+
+class _FusedResnetFC(torch.autograd.Function):
+    """ResnetFC.forward / backward with hand-issued GEMMs (torch -> hipBLASLt) and fused elementwise passes:
+    * the residual stream picks up the biases that are added to it next (fc_1's, lin_z's) in the pass that computes its
+      ReLU, so that fc_1 and lin_z accumulate into it inside the GEMM (beta = 1) -- no separate add pass;
+    * fc_0's bias and ReLU ride in the GEMM epilogue (torch._addmm_activation);
+    * backward: ReLU mask, residual add and the bias gradient (column sums) in one pass; weight gradients as split-K
+      batched GEMMs.
+    Same arithmetic as the module's plain path up to the association of the bias additions."""
+
+    @staticmethod
+    def forward(ctx, zx, d_latent, n_blocks, n_lin_z, *params):
+        W_in, b_in, W_out, b_out = params[:4]
+        blk = [params[4 + 4 * i: 8 + 4 * i] for i in range(n_blocks)]                    # (W0, b0, W1, b1)
+        lz = [params[4 + 4 * n_blocks + 2 * i: 6 + 4 * n_blocks + 2 * i] for i in range(n_lin_z)]  # (Wz, bz)
+        z = zx[:, :d_latent].contiguous()
+        xin = zx[:, d_latent:].contiguous()
+        s = torch.addmm(b_in + lz[0][1] if n_lin_z > 0 else b_in, xin, W_in.t())
+        if n_lin_z > 0:
+            s.addmm_(z, lz[0][0].t())
+        saved = []
+        for i in range(n_blocks):
+            W0, b0, W1, b1 = blk[i]
+            a, xb = _relu_bias(s, b1 + lz[i + 1][1] if i + 1 < n_lin_z else b1)
+            h = torch._addmm_activation(b0, a, W0.t())
+            xb.addmm_(h, W1.t())
+            if i + 1 < n_lin_z:
+                xb.addmm_(z, lz[i + 1][0].t())
+            saved += [s, a, h]
+            s = xb
+        a_out, _ = _relu_bias(s, None, want_xb=False)
+        delta = torch.addmm(b_out, a_out, W_out.t())
+        ctx.save_for_backward(z, xin, s, a_out, *saved, *params)
+        ctx.cfg = (d_latent, n_blocks, n_lin_z)
+        ctx.set_materialize_grads(False)
+        return delta, s
+
+    @staticmethod
+    def backward(ctx, g_delta, g_x):
+        d_latent, n_blocks, n_lin_z = ctx.cfg
+        t = ctx.saved_tensors
+        z, xin, x_last, a_out = t[:4]
+        saved = t[4: 4 + 3 * n_blocks]
+        params = t[4 + 3 * n_blocks:]
+        W_in, b_in, W_out, b_out = params[:4]
+        blk = [params[4 + 4 * i: 8 + 4 * i] for i in range(n_blocks)]
+        lz = [params[4 + 4 * n_blocks + 2 * i: 6 + 4 * n_blocks + 2 * i] for i in range(n_lin_z)]
+        H = W_in.shape[0]
+        dev = z.device
+        grads = [None] * len(params)
+        cs = torch.zeros(H, device=dev)
+        if g_delta is not None:
+            g_delta = g_delta.contiguous()
+            grads[2] = _wgrad(g_delta, a_out)
+            grads[3] = g_delta.sum(0)
+            g = _relu_backward(g_delta @ W_out, x_last, None if g_x is None else g_x.contiguous(), cs)  # dL/d(last block's out)
+        else:  # only the features were used
+            g = g_x.contiguous().clone()
+            cs = g.sum(0)
+        need_in = ctx.needs_input_grad[0]
+        gz = torch.zeros_like(z) if (need_in and n_lin_z > 0) else None
+        for i in reversed(range(n_blocks)):
+            W0, b0, W1, b1 = blk[i]
+            s_i, a_i, h_i = saved[3 * i: 3 * i + 3]
+            k = 4 + 4 * i
+            grads[k + 3] = cs                                 # b1: column sums of dL/d out_i
+            if i + 1 < n_lin_z:                               # lin_z[i+1] fed the same sum
+                kz = 4 + 4 * n_blocks + 2 * (i + 1)
+                grads[kz] = _wgrad(g, z)
+                grads[kz + 1] = cs.clone()
+                if gz is not None:
+                    gz.addmm_(g, lz[i + 1][0])
+            grads[k + 2] = _wgrad(g, h_i)
+            db0 = torch.zeros(H, device=dev)
+            gh = _relu_backward(g @ W1, h_i, None, db0)
+            grads[k + 1] = db0
+            grads[k] = _wgrad(gh, a_i)
+            cs = torch.zeros(H, device=dev)
+            g = _relu_backward(gh @ W0, s_i, g, cs)            # dL/d s_i = dL/d(out of block i-1, + lin_z[i])
+        if n_lin_z > 0:
+            kz = 4 + 4 * n_blocks
+            grads[kz] = _wgrad(g, z)
+            grads[kz + 1] = cs.clone()
+            if gz is not None:
+                gz.addmm_(g, lz[0][0])
+        grads[0] = _wgrad(g, xin)
+        grads[1] = cs
+        g_zx = None
+        if need_in:
+            g_xin = g @ W_in
+            g_zx = torch.cat([gz if gz is not None else torch.zeros_like(z), g_xin], 1)
+        return (g_zx, None, None, None, *grads)
+
+
 class ResnetFC(nn.Module):
     """resnetfc.py:65-177 with combine_layer >= n_blocks, use_spade False, beta 0 (the deformation-field
-    configuration).  zx = [z (d_latent) | x (d_in)]."""
+    configuration).  zx = [z (d_latent) | x (d_in)].  fp32 tensors on a GPU take the fused path (_FusedResnetFC); anything
+    else (CPU, autocast) the plain torch ops below -- the same network either way."""
 
     def __init__(self, d_in, d_out=7, n_blocks=5, d_latent=128, d_hidden=512, combine_layer=3):
         super().__init__()
@@ -146,9 +281,22 @@ class ResnetFC(nn.Module):
         for lin in [self.lin_in, self.lin_out, *self.lin_z]:
             nn.init.constant_(lin.bias, 0.0)
             nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_in")
+        self.fused = True
+
+    def _fusable(self, zx):
+        return (self.fused and zx.is_cuda and zx.dtype == torch.float32 and zx.dim() == 2 and _mlp_ok(self.d_hidden)
+                and not torch.is_autocast_enabled() and self.lin_in.weight.dtype == torch.float32)
 
     def forward(self, zx):
         assert zx.size(-1) == self.d_latent + self.d_in, f"{zx.size(-1)} != {self.d_latent} + {self.d_in}"
+        if self._fusable(zx):
+            n_lin_z = min(self.combine_layer, len(self.lin_z), self.n_blocks)
+            params = [self.lin_in.weight, self.lin_in.bias, self.lin_out.weight, self.lin_out.bias]
+            for b in self.blocks:
+                params += [b.fc_0.weight, b.fc_0.bias, b.fc_1.weight, b.fc_1.bias]
+            for i in range(n_lin_z):
+                params += [self.lin_z[i].weight, self.lin_z[i].bias]
+            return _FusedResnetFC.apply(zx, self.d_latent, self.n_blocks, n_lin_z, *params)
         z, x = zx[..., : self.d_latent], zx[..., self.d_latent:]
         x = self.lin_in(x)
         for i in range(self.n_blocks):

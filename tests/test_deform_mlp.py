@@ -134,3 +134,44 @@ def test_deformation_field_on_gpu_matches_reference_fixture(path):
     _check(grads[1].cpu(), torch.from_numpy(z["grad_z"]), 1e-4, "grad z_feature")
     for (n_, _), g_ in zip(params.items(), grads[2:]):
         _check(g_.cpu(), gp[n_], 1e-4, f"grad {n_}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,hidden,use_x", [(1000, 512, True), (8192, 512, False), (4100, 64, True)])
+def test_fused_resnetfc_equals_the_plain_module_on_gpu(M, hidden, use_x):
+    """The fused path (hand-issued GEMMs + mgs_mlp.hip elementwise passes, split-K weight gradients in the 8192-row case) and the
+    module's plain torch path, both in fp32 with the same non-trivial weights, against the plain path in float64: outputs,
+    input gradient and every parameter gradient -- the fused path must be as close to the exact result as the plain one."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M)
+    deform._WGRAD_MIN_ROWS = 512 if M == 8192 else 4096
+    m = deform.ResnetFC(70, d_hidden=hidden).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():  # the reference's initialisation zeroes fc_1 and the biases: exercise them
+            p.copy_(torch.randn_like(p) * (0.5 / p.shape[-1] ** 0.5 if p.dim() == 2 else 0.1))
+    zx = torch.randn(M, 198, device=dev)
+    wd, wx = torch.randn(M, 7, device=dev), torch.randn(M, hidden, device=dev) / hidden
+
+    def run(mod, fused, dt):
+        mod.fused = fused
+        zin = zx.to(dt).requires_grad_(True)
+        delta, x = mod(zin)
+        loss = (delta * wd.to(dt)).sum() + ((x * wx.to(dt)).sum() if use_x else 0.0)
+        grads = torch.autograd.grad(loss, [zin] + list(mod.parameters()))
+        return [delta.detach().double(), x.detach().double()] + [g.double() for g in grads]
+
+    import copy
+    exact = run(copy.deepcopy(m).double(), False, torch.float64)
+    plain, fused = run(m, False, torch.float32), run(m, True, torch.float32)
+    names = ["delta", "x", "grad zx"] + [f"grad {n}" for n, _ in m.named_parameters()]
+    deform._WGRAD_MIN_ROWS = 4096
+    # A pre-activation within an ulp of zero can land on either side of the ReLU in either fp32 path (the fused one adds
+    # the biases in another order): that row's gradients then differ by a whole term (expected: one flip per ~1e7
+    # activations).  So: 99 % of the elements of every tensor are as close to float64 as the plain path's (x5) or 1e-4 of
+    # the tensor's scale, and every element is within 5 %.
+    for n_, f, p, e in zip(names, fused, plain, exact):
+        scale = float(e.abs().max()) + 1e-12
+        ef, ep = (f - e).abs().flatten(), (p - e).abs().flatten()
+        q = (lambda v: float(torch.quantile(v[:: max(1, v.numel() // 1000000)], 0.99))) if ef.numel() > 100 else (lambda v: float(v.max()))
+        assert q(ef) <= max(5.0 * q(ep), 1e-4 * scale) + 1e-6, (n_, q(ef), q(ep), scale)
+        assert float(ef.max()) <= 5e-2 * scale + 1e-6, (n_, float(ef.max()), scale)
