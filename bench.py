@@ -204,7 +204,9 @@ def main():
         d_color = torch.stack([c for c, _ in cots[:V]])
         d_feat = torch.stack([f for _, f in cots[:V]])
     if deform:  # configs[3]: the deformation field moves the Gaussians before the batched render (scripts/bench_c4.py)
-        from manigaussian_amd.deform import DeformationField
+        from manigaussian_amd.deform import DeformationField, tune_gemms
+        if not os.environ.get("MGS_NO_GEMM_TUNING"):
+            tune_gemms()  # TunableOp: the warm-up steps time hipBLASLt / rocBLAS candidates per GEMM shape (fp32 either way)
         g = torch.Generator().manual_seed(3)
         point_latent = torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
         z_feature = torch.randn(P, 39, generator=g).to(dev)

@@ -34,13 +34,28 @@ __global__ void __launch_bounds__(256) mlp_relu_bwd_kernel(int M, int n4, const 
   const int c4 = threadIdx.x % n4, r0 = threadIdx.x / n4, rstep = 256 / n4;
   const int row_begin = blockIdx.x * MLP_ROWS, row_end = min(M, row_begin + MLP_ROWS);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int r = row_begin + r0; r < row_end; r += rstep) {
-    const size_t i = (size_t)r * n4 + c4;
-    const float4 gp = g_pre[i], av = act[i];
-    float4 g = make_float4(av.x > 0.f ? gp.x : 0.f, av.y > 0.f ? gp.y : 0.f, av.z > 0.f ? gp.z : 0.f, av.w > 0.f ? gp.w : 0.f);
-    if (g_res) { const float4 q = g_res[i]; g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w; }
-    g_out[i] = g;
-    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+  constexpr int U = 4;  // rows in flight per thread: 8-12 independent 16-B loads before the first use
+  for (int rb = row_begin + r0; rb < row_end; rb += U * rstep) {
+    float4 gp[U], av[U], q[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = rb + u * rstep;
+      const size_t i = (size_t)r * n4 + c4;
+      const bool ok = r < row_end;
+      gp[u] = ok ? g_pre[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[u] = ok ? act[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      q[u] = (ok && g_res) ? g_res[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = rb + u * rstep;
+      if (r >= row_end) break;
+      float4 g = make_float4(av[u].x > 0.f ? gp[u].x : 0.f, av[u].y > 0.f ? gp[u].y : 0.f, av[u].z > 0.f ? gp[u].z : 0.f,
+                             av[u].w > 0.f ? gp[u].w : 0.f);
+      g.x += q[u].x; g.y += q[u].y; g.z += q[u].z; g.w += q[u].w;
+      g_out[(size_t)r * n4 + c4] = g;
+      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+    }
   }
   if (!colsum) return;
   red[threadIdx.x] = s;

@@ -11,6 +11,7 @@ Three pieces:
                               contractions, not part of the hand-written path.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -131,6 +132,24 @@ class ResnetBlockFC(nn.Module):
 
 
 # ---- the same network with the elementwise passes fused (mgs_mlp.hip) and the GEMMs issued by hand ------------------
+
+def tune_gemms(enable=True, max_ms=15, iterations=5, filename=None):
+    """Let PyTorch's TunableOp pick the fp32 GEMM kernels (hipBLASLt or rocBLAS) for the MLP's shapes: the first call of
+    every shape times the candidates (a few seconds in total), later calls use the winner.  Measured at configs[3]
+    (M = 100 000, 512 x 512): forward 429 -> 373 us, data gradient 445 -> 363 us per GEMM, 17.9 -> 16.0 ms per step.  Same
+    arithmetic type (fp32 on the matrix cores); process-wide PyTorch state, hence opt-in."""
+    import torch.cuda.tunable as tunable
+    tunable.enable(bool(enable))
+    if enable:
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(int(max_ms))
+        tunable.set_max_tuning_iterations(int(iterations))
+        if filename is None and "PYTORCH_TUNABLEOP_FILENAME" not in os.environ:
+            import tempfile  # TunableOp writes its table at exit: not into the working directory unless asked to
+            filename = os.path.join(tempfile.gettempdir(), f"mgs_tunableop_{os.getpid()}.csv")
+        if filename is not None:
+            tunable.set_filename(filename)
+
 
 def _mlp_ok(n):
     return n % 4 == 0 and (n // 4) <= 256 and 256 % (n // 4) == 0
