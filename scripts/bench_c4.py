@@ -21,6 +21,7 @@ ap.add_argument("--views", type=int, default=4)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--F", type=int, default=32)
 ap.add_argument("--bf16", action="store_true", help="autocast the MLP GEMMs to bf16 (rasterizer stays fp32)")
+ap.add_argument("--no-tune", action="store_true", help="keep hipBLASLt's heuristic GEMM picks (default: TunableOp, deform.tune_gemms)")
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -35,6 +36,9 @@ sc = {k: v.to(dev) for k, v in syn.make_scene(P, F=F, M=4, seed=0).items()}
 g = torch.Generator().manual_seed(3)
 point_latent = torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
 z_feature = torch.randn(P, 39, generator=g).to(dev)
+if not args.no_tune:
+    from manigaussian_amd.deform import tune_gemms
+    tune_gemms()
 field = DeformationField().to(dev)
 with torch.no_grad():  # the reference zero-initialises fc_1; give the deltas some life without exploding the scene
     for p_ in field.parameters():
