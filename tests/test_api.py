@@ -126,3 +126,41 @@ def test_reference_render_file_imports_against_this_module():
     assert mod.GaussianRasterizer is dgr.GaussianRasterizer
     assert list(inspect.signature(mod.render).parameters)[:7] == ["data", "idx", "pts_xyz", "rotations", "scales",
                                                                   "opacity", "bg_color"]
+
+
+def test_async_workspace_guess_follows_the_marks_and_the_headroom():
+    """Host logic of the asynchronous forward (no device): the workspace guess of a shape is its high-water marks times the
+    configurable head-room; marks only grow; an unknown chunk pool means "no guess" (the blocking path is taken)."""
+    from manigaussian_amd import _state
+    import manigaussian_amd as mg
+    st = _state.DeviceState.__new__(_state.DeviceState)  # no pinned memory needed for the marks
+    st.marks = {}
+    key = (1000, 64, 64, 3, 1)
+    assert st.guess(key) is None
+    st.learn(key, R=10000, chunks=None, pool_unknown=True)
+    assert st.guess(key) is None
+    st.learn(key, R=8000, chunks=400)
+    assert st.marks[key] == [10000, 400]
+    assert st.guess(key) == (int(10000 * 1.25) + 4096, int(400 * 1.5) + 64)
+    mg.set_headroom(instances=2.0, chunks=3.0)
+    try:
+        assert st.guess(key) == (2 * 10000 + 4096, 3 * 400 + 64)
+        with pytest.raises(ValueError):
+            mg.set_headroom(instances=0.5)
+    finally:
+        mg.set_headroom(instances=1.25, chunks=1.5)
+
+
+def test_split_k_weight_gradient_equals_the_plain_product():
+    """deform._wgrad: the batched split-K form of g^T @ x used by the fused MLP backward (CPU tensors, float64)."""
+    import torch
+    from manigaussian_amd import deform
+    g, x = torch.randn(4096, 24, dtype=torch.float64), torch.randn(4096, 40, dtype=torch.float64)
+    old = deform._WGRAD_MIN_ROWS
+    try:
+        deform._WGRAD_MIN_ROWS = 64
+        assert torch.allclose(deform._wgrad(g, x), g.t() @ x, rtol=1e-12, atol=1e-12)
+        deform._WGRAD_MIN_ROWS = 10 ** 9
+        assert torch.equal(deform._wgrad(g, x), g.t() @ x)
+    finally:
+        deform._WGRAD_MIN_ROWS = old
