@@ -176,6 +176,12 @@ def _relu_backward(g_pre, act, g_res, colsum):
     return g_pre
 
 
+def _addmm_relu(bias, a, wt):
+    """relu(a @ wt + bias) with bias and ReLU in the GEMM epilogue where this torch has it."""
+    f = getattr(torch, "_addmm_activation", None)
+    return f(bias, a, wt) if f is not None else torch.addmm(bias, a, wt).relu_()
+
+
 _WGRAD_SPLIT = 8        # batches of the split-K weight gradient
 _WGRAD_MIN_ROWS = 4096  # ... taken when each batch still has this many rows
 
@@ -213,7 +219,7 @@ class _FusedResnetFC(torch.autograd.Function):
         for i in range(n_blocks):
             W0, b0, W1, b1 = blk[i]
             a, xb = _relu_bias(s, b1 + lz[i + 1][1] if i + 1 < n_lin_z else b1)
-            h = torch._addmm_activation(b0, a, W0.t())
+            h = _addmm_relu(b0, a, W0.t())
             xb.addmm_(h, W1.t())
             if i + 1 < n_lin_z:
                 xb.addmm_(z, lz[i + 1][0].t())
