@@ -191,6 +191,9 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         key = (P, W, H, F, opts["tight_bins"])
         T = ((W + 15) // 16) * ((H + 15) // 16)
         guess = st.guess(key)
+        cap_worst = P * T  # every Gaussian in every tile
+        if cap_worst < (1 << 30) and L.mgs_binning_bytes2(cap_worst, 0, W, H, F) <= _state.safe_bytes():
+            guess = (cap_worst, L.mgs_chunk_pool_max(cap_worst, W, H))  # cannot overflow: no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and
                 _state.forward_mode() == "async" and opts["bin_mode"] == 1 and T <= 4096)

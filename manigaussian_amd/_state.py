@@ -51,6 +51,23 @@ _HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.25)),
              "chunks": float(os.environ.get("MGS_HEADROOM_CHUNKS", 1.5))}
 
 
+# A shape whose WORST-CASE workspace (every Gaussian in every tile, every chunk of every block visited) stays below this many
+# bytes is always given that workspace: its asynchronous forwards cannot overflow, need no warm-up call and no marks.
+# ManiGaussian's own shape (16 384 Gaussians, 128 x 128, 3 feature channels) needs 206 MB; configs[2] would need 4 GB and
+# goes by the marks instead.
+_SAFE_BYTES = int(float(os.environ.get("MGS_SAFE_WORKSPACE_MB", 1024)) * (1 << 20))
+
+
+def set_safe_workspace(megabytes: float):
+    """Largest worst-case workspace (MB) the asynchronous forward simply allocates instead of guessing from earlier calls."""
+    global _SAFE_BYTES
+    _SAFE_BYTES = int(float(megabytes) * (1 << 20))
+
+
+def safe_bytes() -> int:
+    return _SAFE_BYTES
+
+
 def set_headroom(instances: float = None, chunks: float = None):
     """Factors (>= 1) by which an asynchronous forward's instance list / chunk-record pool exceed the largest count seen."""
     for k, v in (("instances", instances), ("chunks", chunks)):

@@ -78,6 +78,10 @@ class _RasterizeViews(torch.autograd.Function):
             opts = dict(_lib.DEFAULT_OPTIONS)
             key = ("views", V, P, W, H, F, opts["tight_bins"])
             guess = st.guess(key)
+            T1 = ((W + 15) // 16) * ((H + 15) // 16)
+            cap_worst = V * P * T1  # every Gaussian in every tile of every view
+            if 0 < cap_worst < (1 << 30) and L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes():
+                guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))  # cannot overflow
             lazy = (guess is not None and _state.forward_mode() == "async" and opts["bin_mode"] == 1
                     and not s0.prefiltered)
             if capturing and not lazy:

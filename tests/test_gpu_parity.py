@@ -162,7 +162,29 @@ def _raw_forward(d, kwd, P, F, W=128, H=128):
                                   kwd["tanfovy"], H, W, d["shs"], 1, kwd["campos"], False, False, True)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _marks_only():
+    """Size asynchronous forwards from the high-water marks even for shapes whose worst-case workspace is small enough to be
+    allocated outright (the default for them): the tests of the marks / overflow machinery need it."""
+    import manigaussian_amd as mg
+    from manigaussian_amd import _state
+    old = _state.safe_bytes()
+    mg.set_safe_workspace(0)
+    try:
+        yield
+    finally:
+        _state._SAFE_BYTES = old
+
+
 def test_capacity_retry_and_two_call_path_match_fused_forward():
+    with _marks_only():
+        _impl_test_capacity_retry_and_two_call_path_match_fused_forward()
+
+
+def _impl_test_capacity_retry_and_two_call_path_match_fused_forward():
     """The fused forward sizes the binning workspace from a guess; when the guess is too small it reports
     MGS_NEED_CAPACITY and the shim re-bins with the exact count.  The reference-shaped two-call path
     (preprocess -> host read-back -> render) must give the same images as both."""
@@ -225,6 +247,11 @@ def _train_step(d, rast, dC, dF):
 
 
 def test_async_forward_equals_blocking_forward_and_never_synchronises():
+    with _marks_only():
+        _impl_test_async_forward_equals_blocking_forward_and_never_synchronises()
+
+
+def _impl_test_async_forward_equals_blocking_forward_and_never_synchronises():
     """Steady state (third call of a shape onwards): the forward returns without reading anything back -- the workspace
     comes from the high-water marks, the chunk pool is a fraction of the worst case -- and images / gradients are bit
     for bit those of the blocking path (same kernels, same order; only the record indices differ)."""
@@ -266,6 +293,11 @@ def test_async_forward_equals_blocking_forward_and_never_synchronises():
 
 
 def test_async_overflow_is_reported_loudly_and_recovers():
+    with _marks_only():
+        _impl_test_async_overflow_is_reported_loudly_and_recovers()
+
+
+def _impl_test_async_overflow_is_reported_loudly_and_recovers():
     """A scene that outgrows the marks of its shape: the asynchronous forward renders garbage, the next call into the
     library raises, and after that the shape renders correctly again."""
     import manigaussian_amd as mg
@@ -292,6 +324,40 @@ def test_async_overflow_is_reported_loudly_and_recovers():
             mg.check_status(dev)
         assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
         assert st.marks[key][0] >= good[0] and st.marks[key][1] is not None and st.marks[key][1] >= good[1]
+
+
+def test_small_shapes_get_their_worst_case_workspace_and_cannot_overflow():
+    """A shape whose worst-case workspace fits the budget (default 1 GB; ManiGaussian's 16 384 Gaussians need 206 MB) is given
+    that workspace from the first call on: asynchronous immediately, no marks involved, and a scene that is 50 times denser
+    than the previous one of its shape renders correctly (with the marks alone it would overflow and raise)."""
+    import manigaussian_amd as mg
+    from manigaussian_amd import _state
+    dev = torch.device("cuda:0")
+    P, F = 6001, 3  # a shape no other test uses: no marks exist
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    st = _state.device_state(dev)
+    assert (P, 128, 128, F, 1) not in st.marks
+    small = {k: v.to(dev) for k, v in sc.items()}
+    small["scales"] = small["scales"] * 0.05
+    big = {k: v.to(dev) for k, v in sc.items()}
+    big["scales"] = big["scales"] * 4.0
+    outs = {}
+    for name, d in (("small", small), ("big", big)):
+        c, f, r = rast(d["means3D"], torch.zeros(P, 3, device=dev), d["opacities"], shs=d["shs"],
+                       language_feature_precomp=d["language_feature"], scales=d["scales"], rotations=d["rotations"])
+        mg.check_status(dev)  # would raise if the second scene had outgrown a workspace sized from the first
+        outs[name] = (c, f, r)
+    with _marks_only():  # the same two scenes through the blocking path (exact sizes)
+        mg.set_forward_mode("blocking")
+        try:
+            for name, d in (("small", small), ("big", big)):
+                c, f, r = rast(d["means3D"], torch.zeros(P, 3, device=dev), d["opacities"], shs=d["shs"],
+                               language_feature_precomp=d["language_feature"], scales=d["scales"], rotations=d["rotations"])
+                assert torch.equal(c, outs[name][0]) and torch.equal(f, outs[name][1]) and torch.equal(r, outs[name][2])
+        finally:
+            mg.set_forward_mode("async")
+    assert int((outs["big"][2] > 0).sum()) > 0
 
 
 def test_forward_backward_captured_into_a_hip_graph_replays_bit_identically():
