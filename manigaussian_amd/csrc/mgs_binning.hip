@@ -367,8 +367,16 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   constexpr uint32_t CAP = 8192;  // keys staged per group (64 KB)
   __shared__ uint64_t sk[CAP];
   const uint32_t tid = threadIdx.x;
-  const uint4 d = seg_desc[blockIdx.x];
-  if (blockIdx.x >= *n_seg) return;
+  // Workgroup -> segment, XCD-aware: workgroups go to the 8 XCDs round-robin by index and every workgroup stages its WHOLE
+  // tile slice, so the segments of one tile should share an L2.  Runs of 8 consecutive segments (one tile's, mostly) go to
+  // one XCD, the runs round-robin over the XCDs (a contiguous eighth of the list per XCD is unbalanced: dense tiles are
+  // neighbours).  With the identity map the 7 segments of a configs[4] tile ran on 7 XCDs and the kernel fetched 296 MB for
+  // 29 MB of keys (FETCH_SIZE, profiles/r02_sq_counters_c5shape.json).
+  const uint32_t nseg = *n_seg;
+  const uint32_t xj = blockIdx.x >> 3;
+  const uint32_t seg_i = ((xj >> 3) * 8u + (blockIdx.x & 7u)) * 8u + (xj & 7u);
+  if (seg_i >= nseg) return;
+  const uint4 d = seg_desc[seg_i];
   const uint32_t cnt = d.y, start = d.z, L = d.w;
   if (cnt == L) return;  // single-segment slice: bin_segsort_kernel wrote its ids already
   const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);
@@ -423,7 +431,7 @@ static void launch_sort_merge(const BinView& b, const ImgView& im, int R, int T,
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
   hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
                      b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T,
+  hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / 2), 0, s, im.seg_base + T,  // (XCD map)
                      b.seg_desc, b.keys, b.point_list);
 }
 

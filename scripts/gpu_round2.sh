@@ -86,7 +86,7 @@ for W in tests graph trace stats5 multi variants skips bisect noscratch scratch 
                "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE" \
                "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))
-      timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$i -o pmc -- python bench.py --mode eager-st --only-mode --calibrate --steps 10 --warmup 5 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+      timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$i -o pmc -- python bench.py $PMC_BENCH_ARGS --mode eager-st --only-mode --calibrate --steps 10 --warmup 5 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
       echo "pmc pass $i ($grp) rc=$?"
       find $OUT/pmc_$i -name "*kernel_trace.csv" -size +4M -delete
     done
