@@ -6,6 +6,7 @@ torch is plumbing here: it owns device memory (outputs + the three opaque byte w
 reference also returns as uint8 tensors) and supplies the current HIP stream.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -77,11 +78,13 @@ def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefilt
 class ForwardHandle:
     """What a forward leaves for its backward: the filled MgsRasterArgs (reused, not rebuilt), the per-call options and
     the pending device report.  int(handle) blocks until the instance count is known (the reference returns it as an int)."""
-    __slots__ = ("a", "opts", "pending", "R", "keep")
+    __slots__ = ("a", "opts", "pending", "R", "keep", "views", "outs")
 
-    def __init__(self, a, opts, pending, R, keep=None):
+    def __init__(self, a, opts, pending, R, keep=None, views=None, outs=None):
         self.a, self.opts, self.pending, self.R = a, opts, pending, R
-        self.keep = keep  # the tensors whose addresses `a` holds (converted / padded copies would otherwise be freed)
+        self.keep = keep    # the tensors whose addresses `a` holds (converted / padded copies would otherwise be freed)
+        self.views = views  # (MgsView array, V) of a batched forward, else None
+        self.outs = outs    # weak references to (out_color, out_feature): a recovery re-renders into them if they still live
 
     def num_rendered_nowait(self) -> int:
         """The count if the device has reported it, else -1 (never blocks)."""
@@ -108,6 +111,63 @@ class ForwardHandle:
 
 def _capturing() -> bool:
     return torch.cuda.is_current_stream_capturing()
+
+
+def _launch_forward(L, a, views, radii, out_color, out_feat, slot_ptr, stream):
+    """mgs_rasterize_forward / mgs_rasterize_forward_views -> (rc, num_rendered or -1)."""
+    nr = ctypes.c_int32(0)
+    feat_ptr = out_feat.data_ptr() if (out_feat is not None and a.include_feature) else None
+    if views is not None:
+        rc = L.mgs_rasterize_forward_views(ctypes.byref(a), views[1], views[0], radii.data_ptr(), out_color.data_ptr(),
+                                           feat_ptr, ctypes.byref(nr), slot_ptr, stream)
+    else:
+        rc = L.mgs_rasterize_forward(ctypes.byref(a), radii.data_ptr(), out_color.data_ptr(), feat_ptr, ctypes.byref(nr),
+                                     slot_ptr, stream)
+    return rc, int(nr.value)
+
+
+def _weak(t):
+    return None if t is None else weakref.ref(t)
+
+
+def recover_forward(handle, radii, dev):
+    """The asynchronous forward behind `handle` outgrew the workspace that was sized from earlier calls of its shape, and its
+    report arrived before the backward was enqueued: bin and render it AGAIN on the blocking path (a workspace sized from the
+    instance count the device reported, worst-case chunk pool: cannot overflow) into the same output tensors, so that the
+    backward that follows runs on a complete forward state.  The reference can never be in this position
+    (RAST/cuda_rasterizer/rasterizer_impl.cu:284-289 sizes the buffer from the count it waited for); this is the price of
+    not waiting, paid only on the call where a scene grew past its head-room.  What cannot be repaired: whatever was computed
+    from the incomplete images between that forward and this backward (the loss value, its cotangents) -- hence the warning
+    _state issues when it reads the report."""
+    L = _lib.lib()
+    st = _state.device_state(dev)
+    p, a = handle.pending, handle.a
+    V = handle.views[1] if handle.views is not None else 0
+    W, H, F = int(a.W), int(a.H), int(a.F) if a.include_feature else 0
+    R = max(int(p.num_rendered), 0)
+    cap = R + R // 4 + 4096
+    nbytes = L.mgs_views_binning_bytes2(cap, 0, W, H, F, V) if V else L.mgs_binning_bytes2(cap, 0, W, H, F)
+    binning = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    out_color = handle.outs[0]() if handle.outs and handle.outs[0] is not None else None
+    out_feat = handle.outs[1]() if handle.outs and handle.outs[1] is not None else None
+    lead = (V,) if V else ()
+    if out_color is None:
+        out_color = torch.empty(lead + (3, H, W), dtype=_F32, device=dev)
+    if a.include_feature and out_feat is None:
+        out_feat = torch.empty(lead + (F, H, W), dtype=_F32, device=dev)
+    a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool, a.async_forward = binning.data_ptr(), nbytes, cap, 0, 0
+    a.bwd_accum, a.bwd_accum_bytes = None, 0  # the first run's preprocess zeroed the accumulators; nothing touched them since
+    slot_ptr, tag = st.take_slot()
+    a.status_tag = tag
+    rc, R2 = _launch_forward(L, a, handle.views, radii, out_color, out_feat, slot_ptr, _stream(dev))
+    _lib.check(rc, "rasterizer forward (re-run after a workspace overflow)")
+    newp = _state.Pending(a, V, slot_ptr, p.key)
+    st.learn(p.key, R2)
+    st.add(newp)
+    p.recovered = True
+    handle.pending, handle.R = newp, R2
+    handle.keep = (handle.keep, binning)
+    return R2
 
 
 def _grad_layout(L, P, M, F):
@@ -217,41 +277,57 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
                    geom=geom, binning=binning, img=img)
         _lib.fill_options(a, opts)
         slot_ptr, tag = st.take_slot()
-        a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = cap, pool, tag, 1 if lazy else 0
+        # The blocking path leaves binning_capacity at 0: the library then derives the carving from the buffer's BYTE COUNT,
+        # which is all a caller of the reference-shaped pair rasterize_gaussians / rasterize_gaussians_backward(R: int,
+        # binningBuffer) hands back -- forward and backward agree by construction.  The asynchronous path names (capacity,
+        # pool) explicitly and its backward reuses this very struct (ForwardHandle.a).
+        a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = (cap, pool, tag, 1) if lazy else (0, 0, tag, 0)
         grad_buffer = None
         if want_grad_buffer:
             sizes, accum_bytes = _grad_layout(L, P, M, F)
             grad_buffer = torch.empty((sum(sizes),), dtype=_F32, device=dev)
             a.bwd_accum, a.bwd_accum_bytes = grad_buffer.data_ptr(), accum_bytes
         stream = _stream(dev)
-        nr = ctypes.c_int32(0)
         feat_ptr = out_feat.data_ptr() if include_feature else None
-        rc = L.mgs_rasterize_forward(ctypes.byref(a), radii.data_ptr(), out_color.data_ptr(), feat_ptr,
-                                     ctypes.byref(nr), slot_ptr, stream)
-        R = int(nr.value)
+        rc, R = _launch_forward(L, a, None, radii, out_color, out_feat, slot_ptr, stream)
         pending = None
         if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) first call for this shape, or the scene grew: bin + render again
             cap = R + R // 4 + 4096
             binning = torch.empty((L.mgs_binning_bytes2(cap, 0, W, H, F),), **u8)
-            a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning.data_ptr(), binning.numel(), cap, 0
+            a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning.data_ptr(), binning.numel(), 0, 0
             rc = L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(), feat_ptr,
                                                 stream)
             _lib.check(rc, "rasterize_gaussians")
             st.learn(key, R)
         else:
             _lib.check(rc, "rasterize_gaussians")
-            pending = _state.Pending(a, 0, slot_ptr, key, captured=capturing)
-            if capturing:
-                st.captured.append(pending)  # reports at every replay: _state.check_status()
-            else:
-                if R >= 0:
-                    st.learn(key, R)
-                st.pending.append(pending)
+            # a forward that a backward will follow can be repaired there if it overflowed (recover_forward)
+            pending = _state.Pending(a, 0, slot_ptr, key, captured=capturing, recoverable=want_grad_buffer and not capturing)
+            if R >= 0 and not capturing:
+                st.learn(key, R)
+            st.add(pending)  # captured forwards report at every replay: _state.check_status()
         handle = ForwardHandle(a, opts, pending, R, (background, means3D, sh, colors, language_feature, opacity, scales,
-                                                     rotations, cov3D_precomp, viewmatrix, projmatrix, campos))
+                                                     rotations, cov3D_precomp, viewmatrix, projmatrix, campos),
+                               outs=(_weak(out_color), _weak(out_feat) if include_feature and F == F_user else None))
     if include_feature and F != F_user:
         out_feat = out_feat[:F_user].contiguous()
     return handle, out_color, out_feat, radii, geom, binning, img, grad_buffer
+
+
+def _settle(handle, radii, dev, count):
+    """Backward entry: what is known about this backward's forward?  OK or still running: go on (a report that arrives later
+    and says "overflow" raises at the next call into the library: loud, late).  Overflow already known: re-render on the
+    blocking path and go on with a complete state (recover_forward).  Anything else (prefiltered violation): raise."""
+    p = handle.pending
+    if p is None:
+        return count
+    if p.rc == _lib.MGS_NEED_CAPACITY and not p.captured:
+        return recover_forward(handle, radii, dev)
+    if p.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
+        _state.device_state(dev).drain()
+    if p.rc == _lib.MGS_PENDING:
+        p.backward_enqueued = True  # too late to repair: if this forward overflowed, the next drain raises
+    return count
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, language_feature, scales, rotations,
@@ -306,8 +382,7 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
         if handle is not None:  # the forward's arguments, as they were (same tensors: they are saved in the autograd ctx)
             a = handle.a
             count = handle.num_rendered_nowait()
-            if handle.pending is not None and handle.pending.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
-                _state.device_state(dev).drain()  # the forward of this backward overflowed its workspace: say so, loudly
+            count = _settle(handle, radii, dev, count)
         else:
             means3D = _f32c(means3D, "means3D", dev)
             colors = _f32c(colors, "colors_precomp", dev)

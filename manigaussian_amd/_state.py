@@ -18,6 +18,7 @@ import collections
 import ctypes
 import os
 import threading
+import warnings
 
 import torch
 
@@ -47,8 +48,8 @@ def forward_mode() -> str:
 # Head-room of an asynchronous forward's workspace over the high-water marks of its shape: the scene may grow by these
 # factors from one call to the next before a call overflows (and raises, late).  Scenes that differ wildly between calls of
 # one shape (a parity sweep, a data loader mixing scenes) want more, or set_forward_mode("blocking").
-_HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.25)),
-             "chunks": float(os.environ.get("MGS_HEADROOM_CHUNKS", 1.5))}
+_HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.5)),
+             "chunks": float(os.environ.get("MGS_HEADROOM_CHUNKS", 2.0))}
 
 
 # A shape whose WORST-CASE workspace (every Gaussian in every tile, every chunk of every block visited) stays below this many
@@ -79,17 +80,25 @@ def set_headroom(instances: float = None, chunks: float = None):
 
 class Pending:
     """One forward whose device report has not been read yet."""
-    __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured")
+    __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured", "recoverable", "recovered",
+                 "backward_enqueued", "tag", "cap", "pool")
 
-    def __init__(self, a, V, slot_ptr, key, captured=False):
+    def __init__(self, a, V, slot_ptr, key, captured=False, recoverable=False):
         self.a, self.V, self.slot_ptr, self.key = a, V, slot_ptr, key
         self.num_rendered = self.chunks_used = -1
         self.rc = _lib.MGS_PENDING
         self.captured = captured
+        self.recoverable = recoverable    # a backward will follow and can re-render (manigaussian_amd._C.recover_forward)
+        self.recovered = False
+        self.backward_enqueued = False    # ... but it has been enqueued on the incomplete state already
+        # `a` is shared with the forward's handle and is rewritten by a recovery: remember what THIS run was given
+        self.tag, self.cap, self.pool = int(a.status_tag), int(a.binning_capacity), int(a.chunk_pool)
 
     def poll(self):
         """Non-blocking read of the status words; returns the library's code (MGS_PENDING until both words arrived)."""
         if self.rc != _lib.MGS_PENDING:
+            return self.rc
+        if self.recovered:  # its arguments describe the re-run now; this run's verdict is in
             return self.rc
         L = _lib.lib()
         nr, ch = ctypes.c_int32(-1), ctypes.c_int32(-1)
@@ -115,6 +124,7 @@ class DeviceState:
         self.marks = {}      # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
         self.pending = collections.deque()
         self.captured = []   # forwards recorded into HIP graphs: their slots stay reserved, check_status() reads them
+        self.deferred = collections.deque(maxlen=64)  # overflowed forwards whose backward will re-render (diagnostics)
         self.lock = threading.Lock()
 
     def take_slot(self):
@@ -133,6 +143,11 @@ class DeviceState:
             _TAG[0] = (_TAG[0] + 1) & 0xffff
             tag = _TAG[0]
         return ptr, tag
+
+    def add(self, pending):
+        """Register a forward whose report is outstanding (thread-safe: ctypes calls release the GIL)."""
+        with self.lock:
+            (self.captured if pending.captured else self.pending).append(pending)
 
     # ---- high-water marks ---------------------------------------------------------------------------------------
     def guess(self, key):
@@ -159,12 +174,13 @@ class DeviceState:
             return
         failed = None
         synced = False
-        with self.lock:
-            keep = collections.deque()
-            while self.pending:
-                p = self.pending.popleft()
+        with self.lock:  # the deque is only ever mutated under the lock and in place (add() appends under it too)
+            todo = list(self.pending)
+            self.pending.clear()
+            keep = []
+            for i, p in enumerate(todo):
                 rc = p.poll()
-                if rc == _lib.MGS_PENDING and (wait or len(self.pending) + len(keep) >= NSLOTS // 2):
+                if rc == _lib.MGS_PENDING and (wait or (len(todo) - i - 1) + len(keep) >= NSLOTS // 2):
                     if not synced:  # everything enqueued so far has run after this: a report that is still missing never comes
                         torch.cuda.synchronize(self.dev)
                         synced = True
@@ -176,7 +192,7 @@ class DeviceState:
                     keep.append(p)
                     continue
                 failed = self._account(p, rc) or failed
-            self.pending = keep
+            self.pending.extendleft(reversed(keep))  # ahead of anything appended meanwhile (nothing: we hold the lock)
         if failed:
             raise RuntimeError(failed)
 
@@ -186,13 +202,24 @@ class DeviceState:
             self.learn(p.key, p.num_rendered, p.chunks_used)
             return None
         if rc == _lib.MGS_NEED_CAPACITY:
-            over_inst = p.num_rendered > p.a.binning_capacity > 0
+            over_inst = p.num_rendered > p.cap > 0
             self.learn(p.key, p.num_rendered if p.num_rendered >= 0 else None, None, pool_unknown=not over_inst)
-            what = (f"{p.num_rendered} (Gaussian, tile) instances > capacity {p.a.binning_capacity}" if over_inst else
-                    f"chunk pool of {p.a.chunk_pool} records")
-            return ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
-                    f"({what}): the images and gradients of THAT call were incomplete.  The marks are raised; re-run the "
-                    "step, or use manigaussian_amd.set_forward_mode('blocking') for scenes that grow abruptly.")
+            what = (f"{p.num_rendered} (Gaussian, tile) instances > capacity {p.cap}" if over_inst else
+                    f"chunk pool of {p.pool} records")
+            msg = ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
+                   f"({what}): the images of THAT call were incomplete.  The marks are raised")
+            if p.recovered or (p.recoverable and not p.backward_enqueued and not p.captured):
+                # its backward re-renders first (manigaussian_amd._C.recover_forward): the gradients come from a complete
+                # forward; only what the caller computed from the incomplete images in between cannot be repaired
+                if not p.recovered:
+                    self.deferred.append(p)
+                warnings.warn(msg + "; the call's backward re-renders on the blocking path before it runs, but a loss computed "
+                              "from those images was computed from incomplete images.  For scenes that grow abruptly use "
+                              "manigaussian_amd.set_forward_mode('blocking') or a larger set_headroom().", RuntimeWarning,
+                              stacklevel=4)
+                return None
+            return (msg + " and its gradients were computed on the incomplete state; re-run the step, or use "
+                    "manigaussian_amd.set_forward_mode('blocking') for scenes that grow abruptly.")
         return f"rasterizer forward failed: {_lib.last_error()} (code {rc})"
 
     def check_captured(self):

@@ -160,7 +160,7 @@ int mgs_get_option(const char* key) {
 static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 // segment-sort binning keeps per-tile tables in LDS; larger tile grids take the rocPRIM path
 static bool segsort_binning(const Options& o, int T) { return o.bin_mode == 1 && T <= LDS_TILES; }
-size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), &t); return t; }
+size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), 1, &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
 static size_t binning_bytes_T(int R, int pool, int T, int F) {
   size_t t;
@@ -215,7 +215,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
               mgs_geom_bytes(a->P, a->M, a->W, a->H), a->img_bytes, mgs_img_bytes(a->W, a->H));
     return MGS_ERR_WORKSPACE;
   }
-  g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), nullptr);
+  g = carve_geom(a->geom, a->P, a->M, num_tiles(a->W, a->H), 1, nullptr);
   im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
   FwdPreArgs p;
@@ -318,7 +318,7 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   const int F = a->include_feature ? a->F : 0;
   const int T = num_tiles(a->W, a->H);
   const bool segsort = segsort_binning(o, T);
-  GeomView g = carve_geom(a->geom, a->P, a->M, T, nullptr);
+  GeomView g = carve_geom(a->geom, a->P, a->M, T, 1, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
   const BinShape bs = bin_shape(a, T, F);
@@ -398,6 +398,11 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
       a->img_bytes < mgs_img_bytes(a->W, a->H)) {
     set_error("geom/img workspace too small");
     return MGS_ERR_WORKSPACE;
+  }
+  {  // the render forward's counters (chunk records taken, blocks done) may be left over from an earlier render on this
+     // img workspace (the capacity-retry path): reset them; the preprocess's words (flags 0-1, histogram) stay
+    ImgView im = carve_img(a->img, a->W, a->H, nullptr);
+    MGS_HIP(launch_zero_bytes(im.flags + FLAG_CHUNKS_USED, 2 * sizeof(uint32_t), stream), "reset render counters");
   }
   return enqueue_render(a, options_of(a), R, radii, out_color, out_feature, StatusSink{nullptr, 0}, stream);
 }
@@ -511,7 +516,7 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   const int T = num_tiles(a->W, a->H);
   const BinShape bs = bin_shape(a, T, F);
   if (bs.cap < 0 || R > bs.cap) { set_error("backward: binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
-  GeomView g = carve_geom(a->geom, a->P, a->M, T, nullptr);
+  GeomView g = carve_geom(a->geom, a->P, a->M, T, 1, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
   BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
@@ -618,7 +623,7 @@ static RenderArgs views_render_args(const MgsRasterArgs* a, const Options& o, co
 
 size_t mgs_views_geom_bytes(int P, int M, int W, int H, int V) {
   const Atlas at = atlas_of(W, H, V > 0 ? V : 1);
-  size_t t; carve_geom(nullptr, P * at.V, M, at.T, &t); return t;
+  size_t t; carve_geom(nullptr, P * at.V, M, at.T, at.V, &t); return t;
 }
 size_t mgs_views_img_bytes(int W, int H, int V) { const Atlas at = atlas_of(W, H, V > 0 ? V : 1); return mgs_img_bytes(W, at.H); }
 size_t mgs_views_binning_bytes(int R, int W, int H, int F, int V) {
@@ -660,7 +665,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   }
   const BinShape bs = bin_shape(a, at.T, F);
   if (bs.cap < 0) { set_error("binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
-  GeomView g = carve_geom(a->geom, a->P * V, a->M, at.T, nullptr);
+  GeomView g = carve_geom(a->geom, a->P * V, a->M, at.T, V, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   g.flags = im.flags;
   ChunkView cv;
@@ -741,7 +746,7 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
   const BinShape bs = bin_shape(a, at.T, F);
   if (bs.cap < 0 || R > bs.cap) { set_error("backward (views): binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
   const size_t PV = (size_t)a->P * V, P = (size_t)a->P;
-  GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, nullptr);
+  GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, V, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);
   ChunkView cv;
   BinView b = carve_binning(a->binning, bs.cap, at.T, F, bs.pool, &cv, nullptr);

@@ -53,7 +53,7 @@ struct GeomView {
   uint32_t* tiles_touched;  // [P]   (rocPRIM binning only)
   uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched (rocPRIM binning only)
   uint32_t* flags;          // -> ImgView::flags
-  uint32_t* blk_base;       // [ceil(P/PRE_BLOCK)][T]  offset of preprocess workgroup b's instances inside tile t's slice
+  uint32_t* blk_base;       // [preprocess_blocks(P, V)][T]  offset of preprocess workgroup b's instances inside tile t's slice
   void* scan_temp;
   size_t scan_temp_bytes;
 };
@@ -104,7 +104,13 @@ struct ChunkView {
 size_t scan_temp_bytes(int P);
 size_t sort_temp_bytes(int R);
 
-inline GeomView carve_geom(void* p, int P, int M, int T, size_t* total) {
+// P: (virtual) Gaussians = V * Pg for a batch of V views; the preprocess and scatter kernels launch V * ceil(Pg / PRE_BLOCK)
+// workgroups (a workgroup never straddles views), and blk_base has one row per launched workgroup.
+inline size_t preprocess_blocks(size_t P, int V) {
+  const size_t v = V > 0 ? (size_t)V : 1, Pg = (P + v - 1) / v;
+  return v * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
+}
+inline GeomView carve_geom(void* p, int P, int M, int T, int V, size_t* total) {
   Carver c(p);
   GeomView g;
   size_t Pa = P > 0 ? (size_t)P : 1;
@@ -117,7 +123,7 @@ inline GeomView carve_geom(void* p, int P, int M, int T, size_t* total) {
   g.tiles_touched = c.take<uint32_t>(Pa);
   g.point_offsets = c.take<uint32_t>(Pa);
   g.flags = nullptr;
-  g.blk_base = c.take<uint32_t>(((Pa + PRE_BLOCK - 1) / PRE_BLOCK) * (size_t)(T > 0 && T <= LDS_TILES ? T : 0) + 1);
+  g.blk_base = c.take<uint32_t>(preprocess_blocks(Pa, V) * (size_t)(T > 0 && T <= LDS_TILES ? T : 0) + 1);
   g.scan_temp_bytes = scan_temp_bytes((int)Pa);
   g.scan_temp = c.take<char>(g.scan_temp_bytes);
   (void)M;

@@ -26,9 +26,11 @@ __global__ void __launch_bounds__(256) mlp_relu_bias_kernel(size_t total4, int n
 // One workgroup = ROWS consecutive rows; thread t owns the float4 column t % n4 of the rows t / n4, t / n4 + 256 / n4, ...
 // (n4 = N / 4 divides 256): coalesced rows, private column sums, one atomic per column and workgroup at the end.
 constexpr int MLP_ROWS = 128;
-__global__ void __launch_bounds__(256) mlp_relu_bwd_kernel(int M, int n4, const float4* __restrict__ g_pre,
+// g_out may alias g_pre or g_res (the caller runs it in place): none of the three is __restrict__; every thread loads its own
+// elements before it stores them, and no other thread touches them.
+__global__ void __launch_bounds__(256) mlp_relu_bwd_kernel(int M, int n4, const float4* g_pre,
                                                            const float4* __restrict__ act,
-                                                           const float4* __restrict__ g_res, float4* __restrict__ g_out,
+                                                           const float4* g_res, float4* g_out,
                                                            float* __restrict__ colsum) {
   __shared__ float4 red[256];
   const int c4 = threadIdx.x % n4, r0 = threadIdx.x / n4, rstep = 256 / n4;

@@ -233,6 +233,7 @@ class _FusedResnetFC(torch.autograd.Function):
         return delta, s
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_delta, g_x):
         d_latent, n_blocks, n_lin_z = ctx.cfg
         t = ctx.saved_tensors
@@ -245,11 +246,18 @@ class _FusedResnetFC(torch.autograd.Function):
         H = W_in.shape[0]
         dev = z.device
         grads = [None] * len(params)
+        need = ctx.needs_input_grad[4:]  # per parameter: a frozen weight's gradient GEMM is skipped
+
+        def wgrad(k, g, x):
+            if need[k]:
+                grads[k] = _wgrad(g, x)
+
         cs = torch.zeros(H, device=dev)
         if g_delta is not None:
             g_delta = g_delta.contiguous()
-            grads[2] = _wgrad(g_delta, a_out)
-            grads[3] = g_delta.sum(0)
+            wgrad(2, g_delta, a_out)
+            if need[3]:
+                grads[3] = g_delta.sum(0)
             g = _relu_backward(g_delta @ W_out, x_last, None if g_x is None else g_x.contiguous(), cs)  # dL/d(last block's out)
         else:  # only the features were used
             g = g_x.contiguous().clone()
@@ -263,25 +271,26 @@ class _FusedResnetFC(torch.autograd.Function):
             grads[k + 3] = cs                                 # b1: column sums of dL/d out_i
             if i + 1 < n_lin_z:                               # lin_z[i+1] fed the same sum
                 kz = 4 + 4 * n_blocks + 2 * (i + 1)
-                grads[kz] = _wgrad(g, z)
+                wgrad(kz, g, z)
                 grads[kz + 1] = cs.clone()
                 if gz is not None:
                     gz.addmm_(g, lz[i + 1][0])
-            grads[k + 2] = _wgrad(g, h_i)
+            wgrad(k + 2, g, h_i)
             db0 = torch.zeros(H, device=dev)
             gh = _relu_backward(g @ W1, h_i, None, db0)
             grads[k + 1] = db0
-            grads[k] = _wgrad(gh, a_i)
+            wgrad(k, gh, a_i)
             cs = torch.zeros(H, device=dev)
             g = _relu_backward(gh @ W0, s_i, g, cs)            # dL/d s_i = dL/d(out of block i-1, + lin_z[i])
         if n_lin_z > 0:
             kz = 4 + 4 * n_blocks
-            grads[kz] = _wgrad(g, z)
+            wgrad(kz, g, z)
             grads[kz + 1] = cs.clone()
             if gz is not None:
                 gz.addmm_(g, lz[0][0])
-        grads[0] = _wgrad(g, xin)
+        wgrad(0, g, xin)
         grads[1] = cs
+        grads = [g_ if n_ else None for g_, n_ in zip(grads, need)]
         g_zx = None
         if need_in:
             g_xin = g @ W_in

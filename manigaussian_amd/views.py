@@ -115,24 +115,19 @@ class _RasterizeViews(torch.autograd.Function):
                     grad_buffer = torch.empty((sum(sizes),), dtype=_F32, device=dev)
                 if want:
                     a.bwd_accum, a.bwd_accum_bytes = grad_buffer.data_ptr(), accum_bytes
-                nr = ctypes.c_int32(0)
-                rc = L.mgs_rasterize_forward_views(ctypes.byref(a), V, views, radii.data_ptr(), out_color.data_ptr(),
-                                                   out_feat.data_ptr() if inc else None, ctypes.byref(nr),
-                                                   slot_ptr, _C._stream(dev))
-                R = int(nr.value)
+                rc, R = _C._launch_forward(L, a, (views, V), radii, out_color, out_feat if inc else None, slot_ptr,
+                                           _C._stream(dev))
                 if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) the guess was too small: run the batch again with room for R
                     st.learn(key, R)
                     cap, pool = R + R // 4 + 4096, 0
                     continue
                 _lib.check(rc, "rasterize views")
-                pending = _state.Pending(a, V, slot_ptr, key, captured=capturing)
-                if capturing:
-                    st.captured.append(pending)
-                else:
-                    if R >= 0:
-                        st.learn(key, R)
-                    st.pending.append(pending)
-                handle = _C.ForwardHandle(a, opts, pending, R, (views, language_feature))
+                pending = _state.Pending(a, V, slot_ptr, key, captured=capturing, recoverable=want and not capturing)
+                if R >= 0 and not capturing:
+                    st.learn(key, R)
+                st.add(pending)
+                handle = _C.ForwardHandle(a, opts, pending, R, (views, language_feature), views=(views, V),
+                                          outs=(_C._weak(out_color), _C._weak(out_feat) if inc and F == F_user else None))
                 break
         ctx.settings, ctx.num_rendered, ctx.dims = settings, handle, (P, M, F, F_user, V, H, W)
         ctx.grad_buffer = grad_buffer
@@ -174,10 +169,8 @@ class _RasterizeViews(torch.autograd.Function):
             (scratch, d_colors, d_feat, d_means3D, d_means2D, d_opacity, d_cov3D, d_sh, d_scales, d_rot,
              _pad) = flat.split_with_sizes(sizes)
             handle = ctx.num_rendered
-            a, views = handle.a, handle.keep[0]  # the forward's arguments (their tensors are saved in ctx / handle.keep)
-            count = handle.num_rendered_nowait()
-            if handle.pending is not None and handle.pending.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
-                _state.device_state(dev).drain()  # the forward of this backward overflowed its workspace: say so, loudly
+            a, views = handle.a, handle.views[0]  # the forward's arguments (their tensors are saved in ctx / handle.keep)
+            count = _C._settle(handle, radii, dev, handle.num_rendered_nowait())
             a.accum_prezeroed = 1 if prezeroed else 0
             _lib.check(L.mgs_rasterize_backward_views(
                 ctypes.byref(a), V, views, count, radii.data_ptr(), g_color.data_ptr(),

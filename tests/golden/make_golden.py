@@ -40,6 +40,9 @@ def main():
         out.update(out_color=color.numpy(), out_feat=feat.numpy(), radii=radii.numpy(),
                    num_rendered=np.int64(state.num_rendered))
         out.update({f"grad_{k}": v.numpy() for k, v in grads.items()})
+        from oracle import oracle_b  # which pixels / Gaussians hold a pair within 2e-5 of a hard threshold (none, in these)
+        out["fragile_pixels"] = oracle_b.fragile_mask(state).numpy().astype(np.uint8)
+        out["fragile_gaussians"] = oracle_b.fragile_gaussians(state).numpy().astype(np.uint8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "R =", state.num_rendered, "visible =", int((radii > 0).sum()))
 

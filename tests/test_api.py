@@ -141,14 +141,16 @@ def test_async_workspace_guess_follows_the_marks_and_the_headroom():
     assert st.guess(key) is None
     st.learn(key, R=8000, chunks=400)
     assert st.marks[key] == [10000, 400]
-    assert st.guess(key) == (int(10000 * 1.25) + 4096, int(400 * 1.5) + 64)
+    hi, hc = _state._HEADROOM["instances"], _state._HEADROOM["chunks"]
+    assert (hi, hc) == (1.5, 2.0)  # the defaults (memory is cheap on a 288 GB part; an overflow costs a step)
+    assert st.guess(key) == (int(10000 * hi) + 4096, int(400 * hc) + 64)
     mg.set_headroom(instances=2.0, chunks=3.0)
     try:
         assert st.guess(key) == (2 * 10000 + 4096, 3 * 400 + 64)
         with pytest.raises(ValueError):
             mg.set_headroom(instances=0.5)
     finally:
-        mg.set_headroom(instances=1.25, chunks=1.5)
+        mg.set_headroom(instances=hi, chunks=hc)
 
 
 def test_split_k_weight_gradient_equals_the_plain_product():

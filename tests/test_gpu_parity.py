@@ -237,11 +237,13 @@ def _impl_test_capacity_retry_and_two_call_path_match_fused_forward():
                                           None) == _lib.MGS_ERR_WORKSPACE
 
 
-def _train_step(d, rast, dC, dF):
+def _train_step(d, rast, dC, dF, between=None):
     leaves = {k: v.detach().requires_grad_(True) for k, v in d.items()}
     c, f, r = rast(leaves["means3D"], torch.zeros_like(leaves["means3D"]), leaves["opacities"], shs=leaves["shs"],
                    language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
                    rotations=leaves["rotations"])
+    if between is not None:
+        between()
     grads = torch.autograd.grad([c, f], list(leaves.values()), [dC, dF])
     return c, f, r, grads
 
@@ -298,8 +300,15 @@ def test_async_overflow_is_reported_loudly_and_recovers():
 
 
 def _impl_test_async_overflow_is_reported_loudly_and_recovers():
-    """A scene that outgrows the marks of its shape: the asynchronous forward renders garbage, the next call into the
-    library raises, and after that the shape renders correctly again."""
+    """A scene that outgrows the marks of its shape (both kinds: too few instances, too few chunk records).
+    (a) The training-loop case: by the time the backward is reached the forward has long finished (here: a synchronise
+        stands in for the loss and the rest of the network) -- the overflow is known at backward entry, the forward is
+        re-rendered on the blocking path into the same output tensors, NO exception, a RuntimeWarning, and images and
+        gradients equal those of the blocking path.
+    (b) The host-ahead case: forward and backward are both enqueued before the device has reported (they sit behind a
+        long fill) -- the step is lost and the next call into the library raises, loudly.
+    Either way the marks are raised and the shape renders correctly afterwards."""
+    import warnings
     import manigaussian_amd as mg
     from manigaussian_amd import _state
     dev = torch.device("cuda:0")
@@ -308,22 +317,84 @@ def _impl_test_async_overflow_is_reported_loudly_and_recovers():
     d = {k: v.to(dev) for k, v in sc.items()}
     rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
     dC, dF = dC.to(dev), dF.to(dev)
-    for _ in range(3):
+    mg.set_forward_mode("blocking")
+    try:
         c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
+        torch.cuda.synchronize()
+    finally:
+        mg.set_forward_mode("async")
+    for _ in range(3):
+        _train_step(d, rast, dC, dF)
         mg.check_status(dev)
     st = _state.device_state(dev)
     key = (P, W, W, F, 1)
     good = list(st.marks[key])
+
+    def same_as_blocking(c1, f1, r1, g1):
+        assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+        for a, b in zip(g1, g0):
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12  # float atomics: order differs
+
     for bad in ([64, good[1]], [good[0], 1]):   # too few instances / too few chunk records
+        # (a) the report is in before the backward: repaired, not raised
         st.marks[key] = list(bad)
-        with pytest.raises(RuntimeError, match="outgrew the workspace"):
-            _train_step(d, rast, dC, dF)   # the backward may already know (the report arrived) ...
-            mg.check_status(dev)           # ... the next synchronisation point knows for sure
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            c1, f1, r1, g1 = _train_step(d, rast, dC, dF, between=torch.cuda.synchronize)
+            torch.cuda.synchronize()
+            mg.check_status(dev)               # nothing left to raise
+        assert any("outgrew the workspace" in str(x.message) for x in w), [str(x.message) for x in w]
+        same_as_blocking(c1, f1, r1, g1)
+        assert st.marks[key][0] >= good[0]
         for _ in range(3):
             c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
             mg.check_status(dev)
-        assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+        same_as_blocking(c1, f1, r1, g1)
+        assert st.marks[key][1] is not None and st.marks[key][1] >= good[1]
+        # (b) forward AND backward enqueued before the device could report: loud, late
+        st.marks[key] = list(bad)
+        spin = torch.empty(64 << 20, device=dev)
+        with pytest.raises(RuntimeError, match="outgrew the workspace"):
+            for _ in range(20):
+                spin.add_(1.0)
+            _train_step(d, rast, dC, dF)
+            mg.check_status(dev)
+        for _ in range(3):
+            c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
+            mg.check_status(dev)
+        same_as_blocking(c1, f1, r1, g1)
         assert st.marks[key][0] >= good[0] and st.marks[key][1] is not None and st.marks[key][1] >= good[1]
+
+
+def test_raw_C_forward_backward_pair_agrees_with_the_autograd_path():
+    """The reference-shaped pybind pair _C.rasterize_gaussians -> _C.rasterize_gaussians_backward(R: int, binningBuffer)
+    (RAST/rasterize_points.cu:35-225): the backward is handed nothing but the three byte buffers and the count, so forward
+    and backward must derive the same carving from the buffer sizes.  Called twice for one shape: the second forward's
+    buffer is sized from the first one's count (an arbitrary number, not a multiple of 16)."""
+    from manigaussian_amd import _C
+    dev = torch.device("cuda:0")
+    P, F = 7001, 32
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    kwd = syn.camera_settings_kwargs(cam, 1, True, bg=(0.1, 0.2, 0.3), device=dev)
+    dCd, dFd = dC.to(dev), dF.to(dev)
+    e = torch.Tensor([])
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, True, (0.1, 0.2, 0.3))
+    for rep in range(2):
+        R, c, f, radii, geom, binning, img = _raw_forward(d, kwd, P, F)
+        assert isinstance(R, int) and R > 0
+        out = _C.rasterize_gaussians_backward(kwd["bg"], d["means3D"], radii, e, d["language_feature"], d["scales"],
+                                              d["rotations"], 1.0, e, kwd["viewmatrix"], kwd["projmatrix"], kwd["tanfovx"],
+                                              kwd["tanfovy"], dCd, dFd, d["shs"], 1, kwd["campos"], geom, R, binning, img,
+                                              False, True)
+        torch.cuda.synchronize()
+        g_means2D, g_colors, g_feat, g_op, g_means3D, g_cov3D, g_sh, g_scales, g_rot = out
+        assert torch.equal(c.cpu(), ch) and torch.equal(f.cpu(), fh) and torch.equal(radii.cpu(), rh)
+        got = {"means3D": g_means3D, "means2D": g_means2D, "opacities": g_op, "scales": g_scales, "rotations": g_rot,
+               "shs": g_sh, "language_feature": g_feat}
+        for k, v in got.items():
+            ref = gh[k]
+            assert (v.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-12, (rep, k)
 
 
 def test_small_shapes_get_their_worst_case_workspace_and_cannot_overflow():
@@ -383,14 +454,18 @@ def test_golden_vectors(path):
     ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case.get("bg", (0.1, 0.2, 0.3)))
     assert np.array_equal(rh.numpy(), z["radii"])
     pairs = [(ch.numpy(), z["out_color"])] + ([(fh.numpy(), z["out_feat"])] if inc else [])
-    for a, b in pairs:  # no oracle state here: bound the bulk at 1e-4 and any threshold-flip outlier at FRAGILE_TOL
+    # the file carries Oracle B's own fragility masks (pixels / Gaussians with a pair within 2e-5 of a hard threshold):
+    # everything unmarked must meet the contract, the marked ones the flipped-pair bound
+    frag_px, frag_g = z["fragile_pixels"].astype(bool), z["fragile_gaussians"].astype(bool)
+    assert frag_px.mean() <= util.FRAGILE_MAX_FRACTION
+    for a, b in pairs:
         e = np.abs(a - b).max(0)
-        assert np.quantile(e, 0.98) <= IMG_TOL and e.max() <= util.FRAGILE_TOL
+        assert (e[~frag_px].max() if (~frag_px).any() else 0.0) <= IMG_TOL and e.max() <= util.FRAGILE_TOL
     for k, v in gh.items():
         ref = z["grad_" + util.GRAD_KEYS[k]].reshape(v.shape)
-        if ref.size:  # bulk at 1e-3 of the max, a threshold-flip outlier at FRAGILE_GRAD_TOL
+        if ref.size:
             e = np.abs(v.numpy() - ref).reshape(ref.shape[0], -1).max(1)
-            assert np.quantile(e, 0.95) <= GRAD_TOL * np.abs(ref).max() + 1e-7, k
+            assert (e[~frag_g].max() if (~frag_g).any() else 0.0) <= GRAD_TOL * np.abs(ref).max() + 1e-7, k
             assert e.max() <= util.FRAGILE_GRAD_TOL * np.abs(ref).max() + 1e-7, k
 
 
@@ -400,8 +475,9 @@ def _check_against_reference(got, ref, inc, tag, state=None):
     state (an Oracle-B run of the same scene): the library evaluates exp() with v_exp_f32 (relative error ~2e-7), the
     reference with ocml's expf, so a (pixel, Gaussian) pair within that distance of a hard threshold (alpha < 1/255,
     T < 1e-4) may be decided differently -- a handful of pairs among the 10^8..10^9 of the large cases.  The pixels /
-    Gaussians Oracle B marks as sitting within 2e-5 (relative) of such a threshold get FRAGILE_TOL / FRAGILE_GRAD_TOL;
-    everything else the strict bound."""
+    Gaussians Oracle B marks as sitting within 2e-5 (relative) of such a threshold get REF_FRAGILE_TOL (5e-4) /
+    REF_FRAGILE_GRAD_TOL (3e-3 of the max) and at most REF_MAX_PIXELS_ABOVE_CONTRACT pixels of an image may exceed 1e-4;
+    everything else the strict bound (2e-5 / 1e-3).  The measured values go to $MGS_PARITY_REPORT."""
     (ch, fh, rh, gh), (cr, fr, rr, gr) = got, ref
     assert np.array_equal(np.asarray(rh), np.asarray(rr)), tag
     frag_px = frag_g = None
@@ -409,13 +485,18 @@ def _check_against_reference(got, ref, inc, tag, state=None):
         from oracle import oracle_b
         frag_px, frag_g = oracle_b.fragile_mask(state).numpy(), oracle_b.fragile_gaussians(state).numpy()
         assert frag_px.mean() <= util.FRAGILE_MAX_FRACTION, tag
-    for a, b in [(ch, cr)] + ([(fh, fr)] if inc else []):
+    stats = {}
+    for nm, a, b in [("color", ch, cr)] + ([("feature", fh, fr)] if inc else []):
         e = np.abs(np.asarray(a) - np.asarray(b)).max(0)
+        above = int((e > IMG_TOL).sum())
+        stats[nm] = dict(max=float(e.max()), pixels_above_1e_4=above,
+                         max_unmarked=float(e[~frag_px].max()) if frag_px is not None and (~frag_px).any() else float(e.max()))
         if frag_px is None:
-            assert e.max() <= 2e-5, tag
+            assert e.max() <= 2e-5, (tag, nm, e.max())
         else:
-            assert e[~frag_px].max() <= 2e-5, tag
-            assert e.max() <= util.FRAGILE_TOL, tag
+            assert e[~frag_px].max() <= 2e-5, (tag, nm, e[~frag_px].max())
+            assert e.max() <= util.REF_FRAGILE_TOL, (tag, nm, e.max())
+            assert above <= util.REF_MAX_PIXELS_ABOVE_CONTRACT, (tag, nm, above)
     for k, v in gh.items():
         r = np.asarray(gr[util.GRAD_KEYS[k]])
         if k == "language_feature" and not inc:
@@ -423,11 +504,13 @@ def _check_against_reference(got, ref, inc, tag, state=None):
         if r.size:
             e = np.abs(v.numpy() - r.reshape(v.shape)).reshape(v.shape[0], -1).max(1)
             mag = np.abs(r).max()
+            stats["grad_" + k] = dict(max_rel=float(e.max() / (mag + 1e-30)))
             if frag_g is None:
                 assert e.max() <= GRAD_TOL * mag + 1e-7, (tag, k)
             else:
                 assert e[~frag_g].max() <= GRAD_TOL * mag + 1e-7, (tag, k)
-                assert e.max() <= util.FRAGILE_GRAD_TOL * mag + 1e-7, (tag, k)
+                assert e.max() <= util.REF_FRAGILE_GRAD_TOL * mag + 1e-7, (tag, k, e.max() / mag)
+    util.report(tag, against="reference kernels", **stats)
 
 
 @pytest.mark.parametrize("path", REF_GOLDEN, ids=[os.path.basename(p)[:-4] for p in REF_GOLDEN])
@@ -468,6 +551,37 @@ def test_live_reference(case):
     got = util.run_hip(sc, cam, dC, dF, case.get("sh_degree", 1), inc, case.get("bg", (0.1, 0.2, 0.3)))
     state = util.run_oracle_b(sc, kw, dC, dF)[4]  # only to know which pixels sit on a hard threshold
     _check_against_reference(got, (cr, fr, rr, gr), inc, repr(case), state=state)
+    # The integer the reference returns first (RAST/rasterize_points.cu:127 <- rasterizer_impl.cu:282-284): with the
+    # reference's own 3-sigma tile rect (tight_bins = 0) _C.rasterize_gaussians()[0] IS that number; the default
+    # (tight_bins = 1) drops the instances no pixel of the tile can see and returns fewer.
+    R_ref, R_hip = int(R), {}
+    for tight in (0, 1):
+        R_hip[tight] = _num_rendered(sc, cam, case, tight)
+    assert R_hip[0] == R_ref == int(state.num_rendered), (R_hip, R_ref, state.num_rendered)
+    assert 0 < R_hip[1] <= R_ref, (R_hip, R_ref)
+    util.report(repr(case), num_rendered_reference=R_ref, num_rendered_tight0=R_hip[0], num_rendered_tight1=R_hip[1])
+
+
+def _num_rendered(sc, cam, case, tight):
+    """_C.rasterize_gaussians(...)[0] -- the count as the reference's pybind entry point returns it -- under tight_bins."""
+    from manigaussian_amd import _C
+    dev = torch.device("cuda:0")
+    inc = case.get("include_feature", True)
+    kwd = syn.camera_settings_kwargs(cam, case.get("sh_degree", 1), inc, bg=case.get("bg", (0.1, 0.2, 0.3)), device=dev)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    e = torch.Tensor([])
+    old = _lib.get_option("tight_bins")
+    try:
+        _lib.set_option("tight_bins", tight)
+        out = _C.rasterize_gaussians(kwd["bg"], d["means3D"], d.get("colors_precomp", e), d.get("language_feature", e),
+                                     d["opacities"], d.get("scales", e), d.get("rotations", e), 1.0,
+                                     d.get("cov3D_precomp", e), kwd["viewmatrix"], kwd["projmatrix"], kwd["tanfovx"],
+                                     kwd["tanfovy"], kwd["image_height"], kwd["image_width"], d.get("shs", e),
+                                     case.get("sh_degree", 1), kwd["campos"], False, False, inc)
+    finally:
+        _lib.set_option("tight_bins", old)
+    assert isinstance(out[0], int)
+    return out[0]
 
 
 def test_edge_cases_empty_and_all_culled():
@@ -689,6 +803,55 @@ def test_view_batch_equals_per_view_calls(case):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k
 
 
+class _GuardedTorch:
+    """Stand-in for the `torch` module inside manigaussian_amd.views / ._C: every uint8 workspace gets a 64 KB guard band
+    behind the size the library asked for; check() fails if a kernel wrote into one."""
+    GUARD = 64 << 10
+
+    def __init__(self):
+        self.bases = []
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def empty(self, size, *a, **kw):
+        if kw.get("dtype") is torch.uint8:
+            n = int(size[0]) if isinstance(size, (tuple, list)) else int(size)
+            base = torch.empty((n + self.GUARD,), *a, **kw)
+            base[n:] = 0xA5
+            self.bases.append((base, n))
+            return base[:n]
+        return torch.empty(size, *a, **kw)
+
+    def check(self):
+        torch.cuda.synchronize()
+        assert self.bases
+        for base, n in self.bases:
+            assert bool((base[n:] == 0xA5).all()), f"a kernel wrote past a {n}-byte workspace"
+
+
+@pytest.mark.parametrize("P,V,W", [(1100, 4, 128), (1025, 16, 128), (20000, 8, 128), (2049, 3, 64)])
+def test_view_batch_workspaces_are_not_overrun(P, V, W, monkeypatch):
+    """Gaussian counts that are not a multiple of the preprocess workgroup (1024) with V > 1: the per-(workgroup, tile) table
+    has one row per LAUNCHED workgroup, V * ceil(P / 1024), not ceil(V * P / 1024) (round-2 advisor finding: 2-60 KB were
+    written past the geometry workspace).  Guard bands behind every workspace must stay intact, forward and backward."""
+    from manigaussian_amd import views as views_mod, _C as C_mod
+    gt = _GuardedTorch()
+    monkeypatch.setattr(views_mod, "torch", gt)
+    monkeypatch.setattr(C_mod, "torch", gt)
+    F = 32
+    sc, cams, dC, dF = _batch_case(P, F, V, W, W)
+    cb, fb, rb, grads, m2g = _run_batch(sc, cams, dC, dF, (0.1, 0.2, 0.3))
+    gt.check()
+    n_ws = len(gt.bases)
+    assert n_ws >= 3
+    # ... and the single-view path on the same scene (its workspaces are guarded the same way)
+    ch, fh, rh, gh = util.run_hip(sc, cams[0], dC[0], dF[0], 1, True, (0.1, 0.2, 0.3))
+    gt.check()
+    assert len(gt.bases) >= n_ws + 3
+    assert torch.equal(ch, cb[0]) and torch.equal(rh, rb[0])
+
+
 def _batch_case(P, F, V, W, H, seed=2, precomp=False):
     sc = syn.make_scene(P, F=F, M=4, seed=seed, colors_precomp=precomp)
     cams = syn.circle_cameras(max(V, 4), W, H, negative_focal=True)[:V]
@@ -739,18 +902,19 @@ def test_view_batch_matches_reference_kernels(case):
         assert np.array_equal(rb[v].numpy(), rr.numpy()), f"radii, view {v}"
         for nm, a, b in (("color", cb[v], cr), ("feature", fb[v], fr)):
             e = (a - b).abs().max(0)[0]
-            assert e[~fpx].max().item() <= 2e-5 and e.max().item() <= util.FRAGILE_TOL, f"{nm}, view {v}"
+            assert e[~fpx].max().item() <= 2e-5 and e.max().item() <= util.REF_FRAGILE_TOL, f"{nm}, view {v}"
+            assert int((e > IMG_TOL).sum()) <= util.REF_MAX_PIXELS_ABOVE_CONTRACT, f"{nm}, view {v}"
         r2 = gr["means2D"]
         e2 = (m2b[v] - r2).abs().max(1)[0]
         assert e2[~fg].max().item() <= GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
-        assert e2.max().item() <= util.FRAGILE_GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
+        assert e2.max().item() <= util.REF_FRAGILE_GRAD_TOL * r2.abs().max().item() + 1e-9, f"means2D, view {v}"
         acc = {k: t.clone() for k, t in gr.items()} if acc is None else {k: acc[k] + gr[k] for k in acc}
     for k, got in gb.items():
         ref = acc[util.GRAD_KEYS[k]].reshape(got.shape)
         d = (got - ref).abs().reshape(P, -1).max(1)[0]
         mag = ref.abs().max().item()
         assert d[~fragile].max().item() <= GRAD_TOL * mag + 1e-9, k
-        assert d.max().item() <= util.FRAGILE_GRAD_TOL * mag + 1e-9, k
+        assert d.max().item() <= util.REF_FRAGILE_GRAD_TOL * mag + 1e-9, k
 
 
 @pytest.mark.parametrize("case", [dict(P=6000, F=32, V=4, W=128, H=128), dict(P=3000, F=3, V=3, W=72, H=40),

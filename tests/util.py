@@ -98,8 +98,34 @@ def grad_errors(g_hip, g_ref):
     return out
 
 
-FRAGILE_TOL = 1e-2      # a flipped threshold decision moves a pixel by at most ~alpha*T*|c| (alpha ~ 1/255 or T ~ 1e-4)
+# ---- tolerances -----------------------------------------------------------------------------------------------------
+# Contract (BASELINE.json north_star): 1e-4 on images, 1e-3 * max|g| on gradients.  The algorithm has three hard per-pair
+# decisions (alpha < 1/255 -> skip, power > 0 -> skip, T(1-alpha) < 1e-4 -> stop); a pair that sits within float rounding of
+# one of them may legitimately be decided differently by two correct implementations, and a flipped pair moves a pixel by
+# alpha*T*|c| <= |c|/255 ~ 4e-3 (alpha threshold) or ~1e-4*|c| (T threshold).
+#  * against ORACLE B (gcc on the host: another exp(), other FMA contraction) such flips are routine: the pixels / Gaussians
+#    Oracle B itself marks as sitting within 2e-5 (relative) of a threshold get FRAGILE_TOL, everything else the contract.
+#  * against the REFERENCE'S OWN KERNELS on the same GPU the only difference is v_exp_f32 vs ocml expf (2e-7 relative):
+#    measured worst fragile pixel 1.06e-4.  There the bound on marked pixels is REF_FRAGILE_TOL = 5e-4
+#    (~5x the worst case seen), unmarked pixels stay at 2e-5, and the NUMBER of pixels above the 1e-4 contract is capped
+#    by a count (a handful), not by a fraction of the image.
+FRAGILE_TOL = 1e-2
 FRAGILE_MAX_FRACTION = 0.02
+REF_FRAGILE_TOL = 5e-4
+REF_FRAGILE_GRAD_TOL = 3e-3
+REF_MAX_PIXELS_ABOVE_CONTRACT = 8
+
+
+def report(tag, **stats):
+    """Append measured parity statistics to $MGS_PARITY_REPORT (one JSON object per line), so that one GPU run documents how
+    far inside the bounds the implementation sits (profiles/r03_parity_report.jsonl)."""
+    import json
+    import os
+    path = os.environ.get("MGS_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"tag": str(tag)[:160], **{k: (float(v) if isinstance(v, (float, np.floating)) else v)
+                                                         for k, v in stats.items()}}) + "\n")
 
 
 def image_errors(img_hip, img_ref, state, rel_eps=2e-5):
