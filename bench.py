@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Gaussians rasterized/sec (fwd+bwd) on MI355X, BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c5shape|ref16k|c4] [--mode graph|eager|eager-st]
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c5shape|ref16k|c4|c5] [--mode graph|eager|eager-st]
 
 N > 1 without a launcher: the script re-executes itself under `python -m torch.distributed.run --nproc-per-node N`
 (one rank per GPU, RCCL); under a launcher (RANK / WORLD_SIZE set) it checks WORLD_SIZE == N.
@@ -12,14 +12,26 @@ F=32, one look-at view per GPU per step, production negative-focal cameras, inpu
 + one backward of the rasterizer through the public GaussianRasterizer autograd API (+ one all-reduce of the per-Gaussian
 parameter gradients when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
 
-Modes (all three are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default eager-st):
+Modes (all three are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default graph):
+  graph     the step captured once with torch.cuda.graph through the PUBLIC autograd API and replayed (possible because
+            nothing in the library synchronises).  The default: it needs no process-wide torch switch and is what a
+            training loop that cares about a 0.17 ms step would do; one replay costs ~7 us more than the kernels.
   eager-st  the Python step called K times with torch.autograd.set_multithreading_enabled(False): the backward is
-            enqueued by the calling thread.  The library never synchronises (asynchronous forward), so the host runs ahead
-            and the step is GPU-bound: ms_per_step == the sum of the kernel durations of rocprofv3 (profiles/).
+            enqueued by the calling thread, the host runs ahead and the step is GPU-bound: ms_per_step == the sum of the
+            kernel durations of rocprofv3 (profiles/).  A process-global switch, hence not the headline.
   eager     the same with torch's default autograd threading: every backward is handed to the engine's device thread and
-            back (two thread wake-ups per step, ~100 us of idle GPU at this step size).
-  graph     the step captured once with torch.cuda.graph and replayed (possible because nothing in the library
-            synchronises); one replay costs ~7 us more than the eagerly enqueued, already GPU-bound step.
+            back (two thread wake-ups per step): host-bound at this step size, printed beside the headline.
+
+EXACTLY --steps steps are timed for `value` / `ms_per_step` / `steps`.  A K-step region shorter than 50 ms is additionally
+re-measured over a longer region and reported as `long_run` (the short region carries ~0.1 ms of bracket overhead).
+
+Dynamic configs (BASELINE configs[3] / [4], strong scaling: the work of a step is fixed, the ranks share it):
+  c4  100 000 Gaussians, DeformationField (fp32 MLP 70 -> 512 x 5 -> 7) per timestep, 4 timesteps x 4 views = 16 renders per
+      step; rank r takes a contiguous share of the (timestep, view) items (4 GPUs: one timestep x 4 views each).
+  c5  500 000 Gaussians, 256 x 256, F = 32, DeformationField, 8 views per step (8 / N views per GPU: 8, 4, 2, 1).
+  Per timestep on a rank: input assembly (HIP) -> MLP GEMMs (torch / hipBLASLt) + fused elementwise passes (HIP) -> apply
+  (HIP) -> ONE batched render of that rank's views -> l2(rgb) + 0.01 l2(feature) -> backward into the MLP parameters (a flat
+  gradient bucket: the one all-reduce when N > 1, asynchronous) and into point_latent (a local leaf, not reduced).
 
 The JSON line also carries
   roofline      the dominant kernel (render backward) timed live with HIP events on its launch stream; what bounds it
@@ -52,8 +64,10 @@ CONFIGS = {
     "c5shape": dict(P=500000, F=32, size=256, views=1, renders=1, label="configs[4] shape, one view per GPU"),
     "ref16k": dict(P=16384, F=3, size=128, views=1, renders=2,
                    label="ManiGaussian's own step (neural_rendering.py:386-393): 16 384 Gaussians, 2 renders"),
-    "c4": dict(P=100000, F=32, size=128, views=4, renders=1, deform=True,
-               label="configs[3]: deformation MLP (fp32) + 4 views in one batched call per GPU"),
+    "c4": dict(P=100000, F=32, size=128, views=4, timesteps=4, renders=1, deform=True,
+               label="configs[3]: deformation MLP (fp32), 4 timesteps x 4 views = 16 renders per step shared by the ranks"),
+    "c5": dict(P=500000, F=32, size=256, views=8, timesteps=1, renders=1, deform=True,
+               label="configs[4]: 500k Gaussians + deformation MLP (fp32), 8 views per step shared by the ranks"),
 }
 
 
@@ -63,7 +77,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="eager-st", choices=["graph", "eager", "eager-st"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st"])
+    ap.add_argument("--timesteps", type=int, default=None, help="dynamic configs: timesteps per step in total (c4: 4)")
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--F", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
@@ -75,6 +90,9 @@ def parse():
     ap.add_argument("--tight-bins", type=int, default=None)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
                                                       "the N>1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--allreduce", default="dense", choices=["dense", "sparse"],
+                    help="static configs, N > 1: 'sparse' reduces only the rows of Gaussians some rank saw (radii > 0): "
+                         "parallel.sparse_all_reduce_grads -- one host read of the row count per step")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--calibrate", action="store_true", help="counter passes: launch the library's known-instruction-mix "
                                                              "kernel a few times first (scripts/sq_counters.py checks it)")
@@ -120,30 +138,35 @@ def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds):
 
 
 def lib_hash():
-    """Identity of the kernels being timed: a hash over the library's sources (the .so itself is rebuilt per checkout)."""
-    import glob
-    h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "manigaussian_amd", "csrc", "*.h*")) +
-                       [os.path.join(ROOT, "include", "mgsplat.h")]):
-        with open(path, "rb") as f:
-            h.update(os.path.basename(path).encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """Identity of the kernels being timed: the hash of its sources the library carries (mgs_build_id, baked in at compile
+    time by csrc/Makefile) -- of the BINARY that runs, not of the working tree."""
+    from manigaussian_amd import _lib
+    return _lib.build_id()
 
 
-def committed_counters(kernel_substr, so_hash):
-    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r02_sq_counters.json, written by
-    scripts/sq_counters.py from runs of THIS command) -- only if they were collected from the library being timed."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")) as f:
-            j = json.load(f)
-        if j.get("lib_sha256_16") != so_hash:
-            return None, f"profiles/r02_sq_counters.json was collected from library {j.get('lib_sha256_16')}, timing {so_hash}"
-        for k, v in j["kernels"].items():
+COUNTER_FILES = ("r03_sq_counters.json", "r02_sq_counters.json")
+
+
+def committed_counters(kernel_substr, build_id):
+    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r03_sq_counters.json, written by
+    scripts/sq_counters.py from runs of THIS command) -- only if they were collected from the binary being timed."""
+    why = "no committed counters"
+    for name in COUNTER_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                j = json.load(f)
+        except (OSError, ValueError) as e:
+            why = f"{name}: {e}"
+            continue
+        have = j.get("lib_build_id") or j.get("lib_sha256_16")
+        if have != build_id:
+            why = f"profiles/{name} was collected from library {have}, timing {build_id}"
+            continue
+        for k, v in j.get("kernels", {}).items():
             if kernel_substr in k:
                 return v, None
-    except (OSError, KeyError, ValueError) as e:
-        return None, f"no committed counters: {e}"
-    return None, "kernel not in profiles/r02_sq_counters.json"
+        why = f"kernel not in profiles/{name}"
+    return None, why
 
 
 def main():
@@ -155,7 +178,7 @@ def main():
     import torch.distributed as dist
     from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, check_status
     from manigaussian_amd import synthetic as syn
-    from manigaussian_amd.parallel import all_reduce_grads, flat_alias
+    from manigaussian_amd.parallel import all_reduce_grads, flat_alias, sparse_all_reduce_grads
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,42 +204,75 @@ def main():
         _lib.set_option("tight_bins", args.tight_bins)
 
     cfg = dict(CONFIGS[args.config])
-    for k in ("P", "F", "size", "views"):
+    for k in ("P", "F", "size", "views", "timesteps"):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     P, F, W, H, V, NR = cfg["P"], cfg["F"], cfg["size"], cfg["size"], max(1, cfg["views"]), cfg["renders"]
     deform = bool(cfg.get("deform"))
     M = 4
     sc = syn.make_scene(P, F=F, M=M, seed=0)  # identical on every rank: the replicated Gaussian set
-    cams = syn.circle_cameras(max(n_gpus * V * NR, 8), W, H, negative_focal=True)
-    my_cams = [cams[(rank * V * NR + i) % len(cams)] for i in range(V * NR)]
-    cam = my_cams[0]
-    d_color_h, d_feat_h = syn.make_cotangents(W, H, F, seed=1 + rank)
     params = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
-    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-    all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in my_cams]
-    rasts = [GaussianRasterizer(s) for s in all_settings]
-    cots = [tuple(t.to(dev) for t in syn.make_cotangents(W, H, F, seed=1 + rank * V * NR + i)) for i in range(V * NR)]
+    my_items = []  # dynamic configs: this rank's share of the step's (timestep, view) items
+    if deform:
+        # STRONG scaling: the step's work -- T timesteps x V views -- is fixed; rank r takes a contiguous share of the items,
+        # so that the views of one timestep stay together (one MLP evaluation + one batched render per timestep and rank)
+        T_total, V_total = max(1, cfg.get("timesteps", 1)), V
+        items = [(t, v) for t in range(T_total) for v in range(V_total)]
+        if len(items) % n_gpus:
+            raise SystemExit(f"bench.py --config {args.config}: {len(items)} (timestep, view) items do not divide over "
+                             f"{n_gpus} ranks")
+        per = len(items) // n_gpus
+        my_items = items[rank * per:(rank + 1) * per]
+        cams = syn.circle_cameras(max(V_total, 8), W, H, negative_focal=True)
+        renders_total = len(items)
+    else:
+        cams = syn.circle_cameras(max(n_gpus * V * NR, 8), W, H, negative_focal=True)
+        my_cams = [cams[(rank * V * NR + i) % len(cams)] for i in range(V * NR)]
+        renders_total = V * NR * n_gpus
+    cam = cams[0] if deform else my_cams[0]
+    d_color_h, d_feat_h = syn.make_cotangents(W, H, F, seed=1 + rank)
     plist = list(params.values())
-    if V > 1:  # one batched call per step: V views of the same Gaussian set, gradients summed over the views on the device
+    if not deform:
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in my_cams]
+        rasts = [GaussianRasterizer(s) for s in all_settings]
+        cots = [tuple(t.to(dev) for t in syn.make_cotangents(W, H, F, seed=1 + rank * V * NR + i)) for i in range(V * NR)]
+        if V > 1:  # one batched call per step: V views of the same Gaussian set, gradients summed over the views on the device
+            from manigaussian_amd import GaussianRasterizerBatch
+            rast_batch = GaussianRasterizerBatch(all_settings[:V])
+            d_color = torch.stack([c for c, _ in cots[:V]])
+            d_feat = torch.stack([f for _, f in cots[:V]])
+    else:
         from manigaussian_amd import GaussianRasterizerBatch
-        rast_batch = GaussianRasterizerBatch(all_settings[:V])
-        d_color = torch.stack([c for c, _ in cots[:V]])
-        d_feat = torch.stack([f for _, f in cots[:V]])
-    if deform:  # configs[3]: the deformation field moves the Gaussians before the batched render (scripts/bench_c4.py)
         from manigaussian_amd.deform import DeformationField, tune_gemms
+        from manigaussian_amd.parallel import GradBucket
         if not os.environ.get("MGS_NO_GEMM_TUNING"):
             tune_gemms()  # TunableOp: the warm-up steps time hipBLASLt / rocBLAS candidates per GEMM shape (fp32 either way)
         g = torch.Generator().manual_seed(3)
         point_latent = torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
         z_feature = torch.randn(P, 39, generator=g).to(dev)
-        action = torch.randn(1, 8, generator=g).to(dev)
         field = DeformationField().to(dev)
         with torch.no_grad():  # the reference zero-initialises fc_1; give the deltas some life without exploding the scene
             for p_ in field.parameters():
                 p_.mul_(0.05)
-        plist = list(field.parameters()) + [point_latent]
-        tgt_c, tgt_f = torch.rand(V, 3, H, W, generator=g).to(dev), torch.randn(V, F, H, W, generator=g).to(dev)
+        # the MLP's parameter gradients live in ONE flat buffer (the only thing a trainer reduces: point_latent is an
+        # activation of the voxel encoder, a local leaf here); autograd accumulates into it in place over the timesteps
+        # (two of them alternate when N > 1, so that one step's asynchronous all-reduce may overlap the next step)
+        buckets = [GradBucket(dict(field.named_parameters())) for _ in range(2 if world > 1 else 1)]
+        bucket_turn = [0]
+        plist = list(field.parameters())
+        all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in cams]
+        groups = []  # (timestep, batched rasterizer over this rank's views of it, action, targets)
+        for t in sorted({t for t, _ in my_items}):
+            vs = [v for tt, v in my_items if tt == t]
+            gt = torch.Generator().manual_seed(100 + t)
+            groups.append(dict(t=t, views=vs, rast=GaussianRasterizerBatch([all_settings[v] for v in vs]),
+                               action=torch.randn(1, 8, generator=gt).to(dev),
+                               tgt_c=torch.rand(V_total, 3, H, W, generator=gt)[vs].to(dev),
+                               tgt_f=torch.randn(V_total, F, H, W, generator=gt)[vs].to(dev)))
+        n_c, n_f = float(renders_total * 3 * H * W), float(renders_total * F * H * W)  # the loss is a mean over ALL renders
+
+    last_radii = [None]
 
     def render_once(i):
         if V > 1:
@@ -230,16 +286,24 @@ def main():
     def compute_step():
         """forward + backward of this rank's render(s); returns the gradients (views of ONE allocation per render)."""
         if deform:
-            nxt = field(point_latent, z_feature, params["means3D"].detach(), params["shs"].detach(),
-                        params["rotations"].detach(), params["scales"].detach(), params["opacities"].detach(), action=action)
-            color, feat, _ = rast_batch(nxt["xyz"], None, nxt["opacity"], shs=nxt["sh"],
-                                        language_feature_precomp=params["language_feature"].detach(), scales=nxt["scale"],
-                                        rotations=nxt["rot"])
-            loss = ((color - tgt_c) ** 2).mean() + 0.01 * ((feat - tgt_f) ** 2).mean()
-            return torch.autograd.grad(loss, plist)
+            bucket = buckets[bucket_turn[0] % len(buckets)]
+            bucket_turn[0] += 1
+            bucket.attach()       # zero the flat MLP-gradient buffer, point every .grad at its view
+            point_latent.grad = None
+            for gr in groups:     # one timestep: MLP -> apply -> one batched render of this rank's views -> backward
+                nxt = field(point_latent, z_feature, params["means3D"].detach(), params["shs"].detach(),
+                            params["rotations"].detach(), params["scales"].detach(), params["opacities"].detach(),
+                            action=gr["action"])
+                color, feat, _ = gr["rast"](nxt["xyz"], None, nxt["opacity"], shs=nxt["sh"],
+                                            language_feature_precomp=params["language_feature"].detach(),
+                                            scales=nxt["scale"], rotations=nxt["rot"])
+                loss = ((color - gr["tgt_c"]) ** 2).sum() / n_c + 0.01 * ((feat - gr["tgt_f"]) ** 2).sum() / n_f
+                loss.backward()
+            return [bucket.flat]
         out = None
         for i in range(NR):
             color, feat, radii = render_once(i)
+            last_radii[0] = radii
             dc, df = (d_color, d_feat) if V > 1 else cots[i]
             gs = torch.autograd.grad([color, feat], plist, [dc, df])
             out = gs if out is None else out  # NR > 1: the renders are independent; the last ones' gradients stand in
@@ -308,7 +372,12 @@ def main():
                             h.wait()
                     pending.clear()
                     slot = "eager"
-                pending[slot] = all_reduce_grads(grads, async_op=True)
+                if args.allreduce == "sparse" and not deform:
+                    vis = last_radii[0] > 0
+                    sparse_all_reduce_grads(grads, vis.any(0) if vis.dim() == 2 else vis)
+                    pending[slot] = None
+                else:
+                    pending[slot] = all_reduce_grads(grads, async_op=True)
 
     def sync_all():
         for h in list(pending.values()):
@@ -337,13 +406,14 @@ def main():
         torch.autograd.set_multithreading_enabled(mode != "eager-st")
         stepper = Graphed(2 if world > 1 else 1) if mode == "graph" else Eager()
         run(stepper, warmup, collective)
-        el = timed(stepper, steps, collective)
-        if el * 1e3 < MIN_TIMED_MS:  # too little GPU time for a stable clock: extend the timed region, report what was timed
-            steps = int(steps * MIN_TIMED_MS / (el * 1e3) * 1.2) + 1
-            el = timed(stepper, steps, collective)
+        el = timed(stepper, steps, collective)  # EXACTLY the K steps that were asked for
+        long_run = None
+        if el * 1e3 < MIN_TIMED_MS:  # a short region carries the brackets' overhead: measure a longer one BESIDE it
+            k2 = int(steps * MIN_TIMED_MS / (el * 1e3) * 1.2) + 1
+            long_run = (timed(stepper, k2, collective), k2)
         check_status(dev)
         torch.autograd.set_multithreading_enabled(True)
-        return el, steps, stepper
+        return el, steps, stepper, long_run
 
     if args.calibrate:
         sink = torch.empty(256 * 1024, device=dev)
@@ -351,12 +421,13 @@ def main():
             _lib.check(_lib.lib().mgs_calibration_kernel(1000, sink.data_ptr(), None), "calibration")
         torch.cuda.synchronize()
     modes = [args.mode] if args.only_mode else [args.mode] + [m for m in ("graph", "eager", "eager-st") if m != args.mode]
-    results, errors = {}, {}
+    results, errors, long_runs = {}, {}, {}
     headline_stepper = None
     for m in modes:
         try:
-            el, k, stp = measure(m, args.steps, args.warmup)
+            el, k, stp, lr = measure(m, args.steps, args.warmup)
             results[m] = (el, k)
+            long_runs[m] = lr
             if m == args.mode:
                 headline_stepper = stp
         except Exception as e:  # e.g. a graph capture the runtime refuses: report it, keep the other modes
@@ -382,8 +453,11 @@ def main():
         fa = flat_alias(headline_stepper.last) if headline_stepper is not None else None
         ar_bytes = int(fa.numel() * 4) if fa is not None else int(sum(g.numel() for g in headline_stepper.last) * 4)
     if world > 1:  # what the collective costs on top of the compute: the same K steps without it
-        el0, k0, _ = measure(mode, steps, 5, collective=False)
-        exposed_ms = max(0.0, elapsed / steps - el0 / k0) * 1e3
+        el0, k0, _, lr0 = measure(mode, steps, 5, collective=False)
+        lr1 = long_runs.get(mode)
+        with_ms = (lr1[0] / lr1[1]) if lr1 else elapsed / steps
+        without_ms = (lr0[0] / lr0[1]) if lr0 else el0 / k0
+        exposed_ms = max(0.0, with_ms - without_ms) * 1e3
 
     # stage breakdown, untimed extra pass (eager: the stage timers are host-side event records)
     _lib.set_option("profile", 2)
@@ -393,16 +467,25 @@ def main():
     _lib.set_option("profile", 0)
     stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.profile_read(reset=True).items()}
 
-    # measured instance count (R) of this rank's view(s): what one launch of the render kernels processes
-    R = 0
-    if not deform:
-        from manigaussian_amd import _C
-        with torch.no_grad():
-            et = torch.empty(0, device=dev)
-            R = sum(_C.rasterize_gaussians(st.bg, params["means3D"], et, params["language_feature"], params["opacities"],
-                                           params["scales"], params["rotations"], 1.0, et, st.viewmatrix, st.projmatrix,
-                                           st.tanfovx, st.tanfovy, H, W, params["shs"], 1, st.campos, False, False,
-                                           True)[0] for st in all_settings[:V])
+    # measured instance count (R) of what ONE launch of the render kernels covers on this rank
+    from manigaussian_amd import _C
+    launches_per_step = NR
+    with torch.no_grad():
+        et = torch.empty(0, device=dev)
+
+        def count(xyz, rot, st):
+            return _C.rasterize_gaussians(st.bg, xyz, et, params["language_feature"], params["opacities"], params["scales"],
+                                          rot, 1.0, et, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, H, W,
+                                          params["shs"], 1, st.campos, False, False, True)[0]
+        if deform:  # the first timestep's batch of views stands for a launch
+            gr = groups[0]
+            nxt = field(point_latent, z_feature, params["means3D"], params["shs"], params["rotations"], params["scales"],
+                        params["opacities"], action=gr["action"])
+            R = sum(count(nxt["xyz"], nxt["rot"], all_settings[v]) for v in gr["views"])
+            launch_views, launches_per_step = len(gr["views"]), len(groups)
+        else:
+            R = sum(count(params["means3D"], params["rotations"], st) for st in all_settings[:V])
+            launch_views = V
     dev_ids = [None] * world
     if world > 1:
         dist.all_gather_object(dev_ids, torch.cuda.current_device())
@@ -411,43 +494,45 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / steps * 1e3
-        renders = V * NR
-        value = P * renders * n_gpus * steps / elapsed
+        renders = renders_total // n_gpus            # renders per GPU per step
+        value = P * renders_total * steps / elapsed  # whole job: every render of every rank
         bwd_ms, bwd_n = prof["render_bwd"]
         bwd_avg_ms = bwd_ms / max(bwd_n, 1)
-        npix = W * H * V  # pixels one launch covers
+        npix = W * H * launch_views  # pixels one launch covers
         bytes_k8 = R * (112 + 12 * F) + npix * (20 + 4 * F)
         achieved = bytes_k8 / (bwd_avg_ms * 1e-3) / 1e9 if bwd_avg_ms > 0 else 0.0
-        bytes_path = V * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)  # all V views
+        bytes_path = (launch_views * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)) * launches_per_step
         so_hash = lib_hash()
         def roof_block(label, substr, avg_ms, launches, bytes_alg):
-            """What bounds a kernel, from the committed counter passes of THIS library (profiles/r02_sq_counters.json): no
+            """What bounds a kernel, from the committed counter passes of THIS binary (profiles/r03_sq_counters.json): no
             throughput roof is near -- the waves spend their cycles waiting on dependent instructions and on memory / LDS /
             barriers (SQ_WAIT_*).  The HBM line (algorithmic and counter bytes) is kept beside the issue numbers."""
             cnt, why = committed_counters(substr, so_hash)
             traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
             ach = bytes_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             cycles = avg_ms * 1e-3 * 2.4e9  # upper bound: 2.4 GHz peak clock
-            rb = {"kernel": label, "avg_launch_ms": avg_ms, "launches": launches,
-                  "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                          "algorithmic_bytes_per_launch": bytes_alg, "counter_bytes_per_launch": traffic,
-                          "frac_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None},
-                  "traffic": traffic, "counters_note": why, "lib_sha256_16": so_hash}
+            # the contract's block: the HBM line of this kernel -- ALGORITHMIC bytes per launch (SURVEY.md 8d) over the launch
+            # duration measured live with hipEvents on the launch stream, against 8 TB/s; `traffic` = HBM bytes per launch by
+            # the counters (2 * FETCH_SIZE + WRITE_SIZE KiB, the guide's gfx950 correction) from the committed passes
+            rb = {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+                  "algorithmic_bytes_per_launch": bytes_alg,
+                  "frac_by_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
+                  "counters_note": why, "lib_build_id": so_hash}
             if cnt and cnt.get("SQ_INSTS_VALU") and cycles > 0:
+                # beside it, what the counters say actually limits the kernel: no throughput roof is near, the waves wait
                 gips = cnt["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
                 wc = cnt.get("SQ_WAVE_CYCLES") or 0.0
-                rb.update({
-                    "bound": "latency (dependent issue + waits; no throughput roof within 3x)",
-                    "achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s (VALU issue)", "frac": gips / VALU_PEAK_GIPS,
+                rb["limiter"] = {
+                    "summary": "latency (dependent issue + waits): HBM, VALU issue and the matrix pipe are all far from peak",
+                    "valu_issue": {"achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": gips / VALU_PEAK_GIPS},
                     "valu_busy_frac_of_simd_cycles": (cnt.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / (1024 * cycles),
                     "mfma_busy_frac_of_simd_cycles": cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cycles),
                     "wave_cycles_split": {k: (cnt[k] / wc if wc and k in cnt else None)
                                           for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
                     "per_launch": {k: cnt.get(k) for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA",
                                                            "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD",
-                                                           "SQ_INSTS_VMEM_WR")}})
-            else:  # no counters for this binary: only the HBM line can be computed live (the kernels are NOT HBM-bound: DESIGN.md 4)
-                rb.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+                                                           "SQ_INSTS_VMEM_WR")}}
             return rb
 
         roof = roof_block("K8 render backward (gm_bwd_kernel)", "gm_bwd_kernel", bwd_avg_ms, bwd_n, bytes_k8)
@@ -457,25 +542,43 @@ def main():
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",
             "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "mode": mode, "steps_requested": args.steps,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if deform else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "mode": mode,
+            "long_run": ({"steps": long_runs[mode][1], "ms_per_step": long_runs[mode][0] / long_runs[mode][1] * 1e3,
+                          "value": P * renders_total * long_runs[mode][1] / long_runs[mode][0],
+                          "why": f"the {steps}-step region lasted under {MIN_TIMED_MS:.0f} ms; the same stepper over a longer "
+                                 "region (the short one carries ~0.1 ms of barrier + synchronize overhead)"}
+                         if long_runs.get(mode) else None),
             "config": {"workload": f"{cfg['label']}: {P} Gaussians, {W}x{H}, RGB via SH deg 1 (M=4) + {F}-ch language "
                                    f"feature, fwd+bwd, {renders} render{'s' if renders > 1 else ''} per GPU per step"
-                                   f"{' (one batched call)' if V > 1 else ''}, negative-focal look-at cameras",
-                       "name": args.config, "P": P, "W": W, "H": H, "F": F, "M": M, "views_per_gpu": V,
-                       "renders_per_step_per_gpu": renders, "num_rendered_R": int(R), "R_over_P": R / (P * V),
+                                   f"{' (batched calls)' if (V > 1 or deform) else ''}, negative-focal look-at cameras",
+                       "name": args.config, "P": P, "W": W, "H": H, "F": F, "M": M,
+                       "views_per_gpu": (renders if deform else V), "timesteps_per_step": cfg.get("timesteps", 1) if deform else 1,
+                       "renders_per_step_per_gpu": renders, "renders_per_step_total": renders_total,
+                       "render_launch_views": launch_views, "num_rendered_R": int(R), "R_over_P": R / (P * launch_views),
                        "tight_bins": _lib.get_option("tight_bins"),
-                       "collective": "1 in-place all-reduce of the per-Gaussian parameter gradients per step, overlapping "
-                                     "the next step" if n_gpus > 1 else "none"},
+                       "deformation": ("DeformationField per timestep: HIP input assembly -> fp32 MLP 70->512x5->7 (torch GEMMs, "
+                                       "fused HIP elementwise passes) -> HIP apply; gradients of the MLP parameters (one flat "
+                                       "bucket) and of point_latent") if deform else None,
+                       "strong_scaling_recipe": (f"python bench.py --config {args.config} --gpus N for N in "
+                                                 f"{[n for n in (1, 2, 4, 8, 16) if renders_total % n == 0]}: the step's "
+                                                 f"{renders_total} renders are shared, {renders_total}/N per GPU") if deform else None,
+                       "collective": ("none" if n_gpus == 1 else
+                                      "1 asynchronous all-reduce of the flat MLP-gradient bucket per step (point_latent is a "
+                                      "local leaf)" if deform else
+                                      "1 in-place all-reduce of the per-Gaussian parameter gradients per step, overlapping the "
+                                      "next step")},
             "modes_ms_per_step": {m: el / k * 1e3 for m, (el, k) in results.items()}, "mode_errors": errors or None,
             "distributed": {"backend": args.backend if world > 1 else None,
                             "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_ids": dev_ids,
                             "allreduce_bytes_per_step": ar_bytes,
                             "allreduce_exposed_ms_per_step": exposed_ms},
             "roofline": roof, "roofline_fwd": roof_fwd,
-            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path * NR,
-                         "achieved_GBps": bytes_path * NR * n_gpus / (ms_step * 1e-3) / 1e9,
-                         "frac_of_peak": bytes_path * NR / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path,
+                         "achieved_GBps": bytes_path * n_gpus / (ms_step * 1e-3) / 1e9,
+                         "frac_of_peak": bytes_path / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "rasterizer path only (SURVEY.md 8d); the deformation MLP's GEMMs are MFMA work, not in it"
+                                 if deform else "SURVEY.md 8d, whole rasterizer path"},
             "stages_ms": stages,
         }
         if not args.no_cpu_baseline and n_gpus == 1 and not deform:

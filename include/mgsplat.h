@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 4
+#define MGS_ABI_VERSION 5
 
 /* error codes */
 #define MGS_OK 0
@@ -113,6 +113,9 @@ typedef struct MgsRasterArgs {
 
 int mgs_abi_version(void);
 const char* mgs_last_error(void);
+/* 16 hex digits: SHA-256 prefix over the sources this binary was compiled from (csrc/Makefile).  Measurements kept under
+ * profiles/ carry it, so that evidence can be matched to the binary being timed -- not to a working tree. */
+const char* mgs_build_id(void);
 
 /* Process-wide DIAGNOSTICS only -- never results, kernels or layouts (those are MgsOptions, per call).  The one key is
  * "profile": 0 off, 1 hipEvents around the render backward, 2 around every stage (mgs_profile_read). */

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -55,6 +55,7 @@ _EXPORTS = {
     # name: (restype, argtypes)
     "mgs_abi_version": (ctypes.c_int, []),
     "mgs_last_error": (ctypes.c_char_p, []),
+    "mgs_build_id": (ctypes.c_char_p, []),
     "mgs_options_default": (None, [ctypes.POINTER(MgsOptions)]),
     "mgs_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "mgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
@@ -135,6 +136,11 @@ def lib():
             raise ImportError(f"libmgsplat ABI version {v} != expected {ABI_VERSION}; rebuild")
         _lib = L
     return _lib
+
+
+def build_id() -> str:
+    """Hash of the sources libmgsplat.so was compiled from (baked in at build time)."""
+    return lib().mgs_build_id().decode()
 
 
 def last_error() -> str:

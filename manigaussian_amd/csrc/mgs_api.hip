@@ -137,6 +137,10 @@ using namespace mgs;
 extern "C" {
 
 int mgs_abi_version(void) { return MGS_ABI_VERSION; }
+#ifndef MGS_BUILD_ID
+#define MGS_BUILD_ID "unknown"
+#endif
+const char* mgs_build_id(void) { return MGS_BUILD_ID; }
 const char* mgs_last_error(void) { return g_err; }
 
 void mgs_options_default(MgsOptions* o) {

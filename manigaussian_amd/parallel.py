@@ -100,3 +100,38 @@ def all_reduce_grads(grads: Sequence[torch.Tensor], group=None, async_op: bool =
         g.copy_(bucket[off:off + g.numel()].view_as(g))
         off += g.numel()
     return None
+
+
+def sparse_all_reduce_grads(grads: Sequence[torch.Tensor], visible: torch.Tensor, group=None) -> int:
+    """The same sum as all_reduce_grads, moving only the rows that can be non-zero (lever 2 of DESIGN.md 7).
+
+    grads:   per-Gaussian gradient tensors of one step, each [P, ...] (means3D, opacity, SH, scales, rotations, features ...)
+    visible: bool [P] on this rank -- radii > 0 in ANY view this rank rendered.  A Gaussian that no rank saw has an all-zero
+             gradient row on every rank (the backward writes zeros for radii == 0, RAST/rasterize_points.cu:167-184 zero
+             initialises them), so leaving those rows out of the reduction is exact.
+    Cost model: one small all-reduce of the mask (4 P bytes), one host read of the row count (the ranks must agree on the
+    packed size), a gather / scatter pass over the visible rows, and an all-reduce of K x D floats instead of P x D.  At
+    BASELINE configs[2] about 60 % of the Gaussians are visible per view; the saving grows with the number of ranks (ring
+    all-reduce is per-link bound on xGMI) and shrinks with the number of views per rank.  Returns K."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return int(visible.sum().item())
+    gs = [g for g in grads if g is not None and g.numel() > 0]
+    P = int(visible.numel())
+    for g in gs:
+        if g.shape[0] != P or not g.is_contiguous():
+            raise ValueError("sparse_all_reduce_grads takes contiguous per-Gaussian tensors [P, ...]")
+    seen = visible.to(torch.int32)
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM, group=group)   # union over the ranks
+    idx = (seen > 0).nonzero(as_tuple=False).squeeze(1)        # host synchronisation: every rank learns the same K
+    K = int(idx.numel())
+    if K == 0:
+        return 0
+    rows = [g.view(P, -1) for g in gs]
+    packed = torch.cat([r.index_select(0, idx) for r in rows], dim=1)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for r in rows:
+        w = r.shape[1]
+        r.index_copy_(0, idx, packed[:, off:off + w])
+        off += w
+    return K

@@ -1,8 +1,8 @@
-"""rocprofv3 --pmc passes -> profiles/r02_sq_counters.json: per-kernel, per-launch averages of every counter collected, after
+"""rocprofv3 --pmc passes -> profiles/r03_sq_counters.json: per-kernel, per-launch averages of every counter collected, after
 VALIDATING each pass against the library's calibration kernel (mgs_calibration_kernel: per wave and iteration exactly
 64 v_fma_f32 + 8 v_mfma_f32_32x32x2_f32 + 4 ds_read_b32; 256 workgroups x 4 waves x 1000 iterations).
 
-  python scripts/sq_counters.py <out.json> <lib hash> <pass dir> [<pass dir> ...]
+  python scripts/sq_counters.py <out.json> <mgs_build_id() of the library that ran> <pass dir> [<pass dir> ...]
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
 (FETCH_SIZE tallies 128-B requests at 64 B).  A pass whose calibration counts are off by more than 3 % is dropped and
@@ -66,8 +66,8 @@ def main():
             # quad-cycles of VALU issue summed over waves / (SIMDs x busy cycles): how full the VALU issue slots were
             c["note"] = "SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md)"
     json.dump({"source": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py --mode eager-st --only-mode --calibrate "
-                         "--steps 10 --warmup 5 --no-cpu-baseline (one counter group per pass; scripts/gpu_round2.sh)",
-               "lib_sha256_16": so_hash, "calibration_checks": checks, "rejected_passes": rejected,
+                         "--steps 10 --warmup 5 --no-cpu-baseline (one counter group per pass; scripts/gpu_round3.sh)",
+               "lib_build_id": so_hash, "calibration_checks": checks, "rejected_passes": rejected,
                "hbm_correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
                "kernels": kernels}, open(out_path, "w"), indent=1)
     print(json.dumps({k: {n: round(v) for n, v in c.items() if isinstance(v, float)} for k, c in kernels.items()

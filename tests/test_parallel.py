@@ -115,6 +115,38 @@ def test_all_reduce_grads_aliasing_and_staging(tmp_path):
     assert torch.equal(got["c"], torch.full((3,), 3.0)) and torch.equal(got["d"], torch.full((2, 2), 3.0))
 
 
+def _sparse_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from manigaussian_amd.parallel import all_reduce_grads, sparse_all_reduce_grads
+    P = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    visible = torch.rand(P, generator=g) < 0.4           # each rank saw another 40 % of the Gaussians
+    shapes = [(P, 3), (P, 1), (P, 4, 3), (P, 3), (P, 4), (P, 32)]   # means3D, opacity, SH, scales, rotations, features
+    grads = [torch.randn(*s, generator=g) * visible.reshape(-1, *([1] * (len(s) - 1))) for s in shapes]
+    dense = [t.clone() for t in grads]
+    all_reduce_grads(dense)
+    K = sparse_all_reduce_grads(grads, visible)
+    if rank == 0:
+        torch.save(dict(K=K, visible=visible, sparse=grads, dense=dense), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sparse_visible_row_reduce_equals_the_dense_sum(tmp_path):
+    """parallel.sparse_all_reduce_grads: only rows some rank saw (radii > 0) travel; the result is the dense all-reduce's,
+    bit for bit (two ranks: a + b in both), and K = |union of the visible sets|."""
+    out = str(tmp_path / "sparse.pt")
+    mp.start_processes(_sparse_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out)
+    v1 = torch.rand(1000, generator=torch.Generator().manual_seed(101)) < 0.4
+    assert got["K"] == int((got["visible"] | v1).sum()) and 0 < got["K"] < 1000
+    for a, b in zip(got["sparse"], got["dense"]):
+        assert torch.equal(a, b)
+
+
 # ---- bench.py --gpus N: the driver's command shape must launch N ranks by itself ------------------------------------------
 
 def _bench(args, timeout=600):
@@ -154,6 +186,32 @@ def test_bench_self_launches_two_ranks_on_one_device():
     assert j["n_gpus"] == 2 and j["distributed"]["world_size_seen"] == 2 and len(j["distributed"]["device_ids"]) == 2
     assert j["distributed"]["allreduce_bytes_per_step"] == 20000 * (3 + 1 + 12 + 3 + 4 + 32) * 4
     assert j["distributed"]["allreduce_exposed_ms_per_step"] is not None and j["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg,ranks", [("c4", 1), ("c4", 2), ("c5", 2)])
+def test_bench_dynamic_configs_share_the_step_between_ranks(cfg, ranks):
+    """BASELINE configs[3] / [4] as `bench.py --config c4 | c5` runs them (at a reduced Gaussian count, the shapes and the
+    control flow are the real ones): the step's (timestep, view) renders are SHARED by the ranks (strong scaling), every
+    rank reduces exactly the flat MLP-gradient bucket, and the line says so."""
+    env_flags = ["--one-device", "--backend", "gloo"] if ranks > 1 else []
+    os.environ["MGS_NO_GEMM_TUNING"] = "1"
+    try:
+        r, j = _bench(["--config", cfg, "--gpus", str(ranks), "--P", "6000", "--steps", "3", "--warmup", "2", "--mode",
+                       "eager-st", "--only-mode", "--no-cpu-baseline"] + env_flags, timeout=800)
+    finally:
+        del os.environ["MGS_NO_GEMM_TUNING"]
+    assert r.returncode == 0 and j is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    total = {"c4": 16, "c5": 8}[cfg]
+    c = j["config"]
+    assert j["n_gpus"] == ranks and j["scaling"] == "strong" and j["steps"] == 3
+    assert c["renders_per_step_total"] == total and c["renders_per_step_per_gpu"] == total // ranks
+    assert j["value"] > 0 and abs(j["value"] - 6000 * total * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
+    if ranks > 1:
+        from manigaussian_amd.deform import DeformationField
+        n_params = sum(p.numel() for p in DeformationField().parameters())
+        assert j["distributed"]["allreduce_bytes_per_step"] == 4 * n_params  # the MLP's gradients, nothing else
 
 
 @pytest.mark.gpu

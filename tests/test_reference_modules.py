@@ -1,0 +1,379 @@
+"""Parity pins against the reference's own PYTHON modules either side of the rasterizer (SURVEY.md 8a rows a14-a16, 8f rows
+2-4), executed unmodified (tests/ref_import.py: from /root/reference, or from the build-time byte copies oracle/_ref/mg/ on
+the GPU box) or through the committed fixtures they produced (tests/golden/mg/*.npz, tests/golden/make_golden_mg.py):
+
+  agents/manigaussian_bc/models_embed.py:GeneralizableGSEmbedNet.forward      -> voxel gather + positional code (f3), regressor
+                                                                                epilogue (f2), deformation input assembly
+                                                                                (a14), MLP (a15), apply (a16)
+  agents/manigaussian_bc/neural_rendering.py:NeuralRenderer.get_novel_calib   -> camera calibration (f4)
+  + graphics_utils.py:17-53
+
+CPU tests (-m "not gpu"): the fixtures are what the live modules produce today; the HOST calibration entry point
+(mgs_novel_calib_host is host code of the product library) against the camera fixture.
+GPU tests (-m gpu): every kernel against the fixtures, against the live modules at production size (d_hidden 512, 16 384
+points), and the WHOLE dynamic step -- reference embed net -> V runs of the reference's rasterizer kernels (oracle/_ref)
+-> loss -> gradients of every deformation-MLP parameter and of point_latent -- against DeformationField ->
+GaussianRasterizerBatch (BASELINE.json configs[3] / configs[4]; test_dynamic_step_matches_reference).
+"""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import ref_embed
+import ref_import
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMBED = sorted(glob.glob(os.path.join(HERE, "golden", "mg", "embed_*.npz")))
+CALIB = os.path.join(HERE, "golden", "mg", "novel_calib.npz")
+BOUNDS = (-0.3, -0.5, 0.6, 0.7, 0.5, 1.6)     # conf/method/ManiGaussian_BC.yaml:124
+FREQ = 1.5                                     # conf/method/ManiGaussian_BC.yaml:161 (code.freq_factor)
+
+
+def _case(z):
+    return eval(bytes(z["case"]).decode())
+
+
+def _need_reference():
+    if not ref_import.have_reference():
+        pytest.skip("neither /root/reference nor oracle/_ref/mg (built by `make -C oracle` where the reference exists)")
+
+
+# ------------------------------------------------------------------ CPU: the fixtures are the reference's outputs
+
+@pytest.mark.parametrize("path", EMBED, ids=[os.path.basename(p)[:-4] for p in EMBED])
+def test_embed_fixture_is_what_the_reference_module_computes(path):
+    _need_reference()
+    z = np.load(path)
+    c = _case(z)
+    net = ref_embed.build_net(c["d_hidden"], use_action=c["use_action"], semantic=c["semantic"], seed=c["seed"])
+    net.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}, strict=True)
+    data = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    data.update(next={}, step=10000)
+    cots = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("cot_")}
+    r = ref_embed.run(net, data, cotangents=cots)
+    for k in ref_embed.OUT_KEYS:
+        assert np.allclose(r.data[k].detach().numpy(), z["out_" + k], rtol=1e-5, atol=1e-6), k
+    for k in ("xyz_maps", "rot_maps"):
+        assert np.allclose(r.data["next"][k].detach().numpy(), z["next_" + k], rtol=1e-5, atol=1e-6), k
+    for k, v in r.probe.items():
+        assert np.allclose(v.detach().numpy(), z["probe_" + k], rtol=1e-5, atol=1e-6), k
+    for k in ("dec_fts", "raw", "delta", "point_latent"):
+        g = z["grad_" + k]
+        assert np.abs(r.grad[k].numpy() - g).max() <= 1e-4 * np.abs(g).max() + 1e-7, k
+
+
+def _calib_cases():
+    z = np.load(CALIB)
+    names = sorted({k.split("/")[0] for k in z.files})
+    return z, names
+
+
+def _spec(z, name):
+    W, H, zn, zf, tx, ty, tz, scale = z[name + "/spec"].tolist()
+    return int(W), int(H), zn, zf, (tx, ty, tz), scale
+
+
+def test_calibration_fixture_is_what_get_novel_calib_computes():
+    _need_reference()
+    NR = ref_import.load_neural_rendering()
+    z, names = _calib_cases()
+    for name in names:
+        W, H, zn, zf, trans, scale = _spec(z, name)
+        self_ = types.SimpleNamespace(W=W, H=H, znear=zn, zfar=zf, trans=list(trans), scale=scale)
+        nv = NR.NeuralRenderer.get_novel_calib(self_, dict(intr=torch.from_numpy(z[name + "/K"].astype(np.float64)),
+                                                           extr=torch.from_numpy(z[name + "/c2w"])))
+        for k in ("FovX", "FovY", "world_view_transform", "full_proj_transform", "camera_center"):
+            assert np.allclose(nv[k].numpy(), z[name + "/" + k], rtol=1e-6, atol=1e-7), (name, k)
+
+
+def _check_calib(got, z, name):
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        r = z[name + "/" + k]
+        assert np.abs(np.asarray(got[k]) - r).max() <= 2e-6 * max(1.0, np.abs(r).max()), (name, k)
+    fov = np.asarray(got["fov"])
+    assert np.abs(fov[:, 0] - z[name + "/FovX"]).max() <= 1e-6 and np.abs(fov[:, 1] - z[name + "/FovY"]).max() <= 1e-6
+    tan_ref = np.tan(np.stack([z[name + "/FovX"], z[name + "/FovY"]], 1).astype(np.float64) * 0.5)
+    assert np.abs(np.asarray(got["tanfov"]) - tan_ref).max() <= 2e-6 * np.abs(tan_ref).max()
+    assert ((z[name + "/FovX"] < 0) == (z[name + "/K"][:, 0, 0] < 0)).all()  # negative focal lengths stay negative (a7)
+
+
+def test_host_calibration_matches_the_reference_fixture():
+    """mgs_novel_calib_host (the routine a data-loader cache calls once per camera file) against
+    NeuralRenderer.get_novel_calib's outputs: both focal signs, off-centre principal points, (trans, scale) != identity."""
+    from manigaussian_amd import camera
+    z, names = _calib_cases()
+    assert len(names) == 3
+    for name in names:
+        W, H, zn, zf, trans, scale = _spec(z, name)
+        got = camera.novel_calib_host(z[name + "/c2w"], z[name + "/K"], W, H, zn, zf, trans, scale)
+        _check_calib(got, z, name)
+
+
+def test_bench_camera_generator_matches_the_reference_fixture():
+    """manigaussian_amd.synthetic.novel_calib builds the cameras of bench.py and of the parity tests (a numpy/torch
+    restatement that lives beside the synthetic scene generator): it must be what get_novel_calib computes, too."""
+    from manigaussian_amd import synthetic as syn
+    z, names = _calib_cases()
+    for name in names:
+        W, H, zn, zf, trans, scale = _spec(z, name)
+        if trans != (0.0, 0.0, 0.0) or scale != 1.0:
+            continue
+        for v in range(z[name + "/c2w"].shape[0]):
+            r = syn.novel_calib(z[name + "/c2w"][v], z[name + "/K"][v].astype(np.float64), W, H, zn, zf)
+            for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+                assert np.allclose(r[k].numpy(), z[name + "/" + k][v], rtol=1e-6, atol=1e-7), (name, v, k)
+            assert abs(r["FovX"] - float(z[name + "/FovX"][v])) <= 1e-6 and abs(r["FovY"] - float(z[name + "/FovY"][v])) <= 1e-6
+
+
+# ------------------------------------------------------------------ GPU: kernels against the fixtures
+
+def _dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_device_calibration_matches_the_reference_fixture():
+    from manigaussian_amd import camera
+    dev = _dev()
+    z, names = _calib_cases()
+    for name in names:
+        W, H, zn, zf, trans, scale = _spec(z, name)
+        data = {"intr": torch.from_numpy(z[name + "/K"]).to(dev), "extr": torch.from_numpy(z[name + "/c2w"]).to(dev)}
+        nv = camera.get_novel_calib(data, W, H, zn, zf, trans, scale)
+        got = dict(world_view_transform=nv["world_view_transform"].cpu(), full_proj_transform=nv["full_proj_transform"].cpu(),
+                   camera_center=nv["camera_center"].cpu(), fov=torch.stack([nv["FovX"], nv["FovY"]], 1).cpu(),
+                   tanfov=nv["tanfov"].cpu())
+        _check_calib(got, z, name)
+        assert torch.equal(nv["width"].cpu(), torch.from_numpy(z[name + "/width"]))
+
+
+def _close(a, b, rel, what):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= rel * max(b.abs().max().item(), 1e-30) + 1e-7, (what, err, b.abs().max().item())
+
+
+def _check_kernels_against(ref, use_semantic, dev, tol=1e-5, gtol=1e-4):
+    """ref: namespace with .inputs (xyz, dec_fts, action), .out (the module's maps), .next, .probe, .cot, .grad --
+    from a fixture or from a live run.  Every HIP kernel on the path is fed the reference's own intermediate and must
+    reproduce the reference's next intermediate and, backward, the gradient the reference left on its input."""
+    from manigaussian_amd.deform import assemble_deform_input, deform_apply
+    from manigaussian_amd.regressor import gaussian_epilogue
+    from manigaussian_amd.voxel import point_latent_pe
+    t = lambda a: torch.as_tensor(a).to(dev)  # noqa: E731
+    N = ref.inputs["xyz"].shape[1]
+    # ---- f3: voxel gather + positional code == the encoder's input; backward into the voxel features
+    vox = t(ref.inputs["dec_fts"]).requires_grad_(True)
+    lat = point_latent_pe(vox, t(ref.inputs["xyz"]), BOUNDS, num_freqs=6, freq_factor=FREQ)
+    _close(lat[:, :128], ref.probe["point_latent"].reshape(N, 128), tol, "point_latent")
+    _close(lat[:, 128:131], ref.probe["latent_in"][:, 128:131], tol, "canonical xyz")
+    assert (lat[:, 131:].cpu() - torch.as_tensor(ref.probe["latent_in"][:, 131:])).abs().max().item() <= 2e-5, "positional code"
+    g_lat = torch.zeros_like(lat)
+    g_lat[:, :128] = t(ref.grad["point_latent"]).reshape(N, 128)
+    lat.backward(g_lat)
+    _close(vox.grad, ref.grad["dec_fts"], gtol, "d/d dec_fts (grid_sample backward)")
+    # ---- f2: regressor epilogue on the reference's raw 26-vector
+    raw = t(ref.probe["raw"]).requires_grad_(True)
+    ep = gaussian_epilogue(raw, t(ref.inputs["xyz"]))
+    names = dict(xyz="xyz_maps", sh="sh_maps", rot="rot_maps", scale="scale_maps", opacity="opacity_maps", feature="feature_maps")
+    for k, rk in names.items():
+        _close(ep[k], ref.out[rk], tol, "epilogue " + k)
+    feat = torch.as_tensor(ref.out["feature_maps"])
+    _close(ep["feature_normalized"], feat / (feat.norm(dim=-1, keepdim=True) + 1e-12), tol,
+           "feature L2 norm (gaussian_renderer/__init__.py:66-68)")
+    sum((ep[k] * t(ref.cot[rk])).sum() for k, rk in names.items()).backward()
+    _close(raw.grad, ref.grad["raw"], gtol, "d/d raw (epilogue backward)")
+    # ---- a14: input assembly from the reference's maps == dyna_input, bit for bit (a gather-concat)
+    o = {k: t(v) for k, v in ref.out.items()}
+    pl = t(ref.probe["point_latent"]).reshape(N, 128).requires_grad_(True)
+    zf = t(ref.probe["latent_in"][:, 128:]).contiguous()
+    dyn = assemble_deform_input(pl, zf, o["xyz_maps"][0], o["sh_maps"][0], o["rot_maps"][0], o["scale_maps"][0],
+                                o["opacity_maps"][0], o["feature_maps"][0] if use_semantic else None,
+                                t(ref.inputs["action"]) if "action" in ref.inputs else None)
+    assert torch.equal(dyn.cpu(), torch.as_tensor(ref.probe["dyna_input"])), "dyna_input (models_embed.py:258-287)"
+    dyn.backward(t(ref.grad["dyna_input"]))
+    _close(pl.grad, ref.grad["dyna_input"][:, :128], 1e-7, "d/d point_latent through the assembly")
+    # ---- a16: apply on the reference's delta == next.{xyz,rot}; backward == the gradient on delta
+    delta = t(ref.probe["delta"]).reshape(N, 7).requires_grad_(True)
+    nx, nr = deform_apply(delta, o["xyz_maps"][0], o["rot_maps"][0])
+    _close(nx, ref.next["xyz_maps"][0], tol, "next.xyz")
+    _close(nr, ref.next["rot_maps"][0], tol, "next.rot")
+    ((nx * t(ref.cot["next_xyz_maps"])[0]).sum() + (nr * t(ref.cot["next_rot_maps"])[0]).sum()).backward()
+    _close(delta.grad, torch.as_tensor(ref.grad["delta"]).reshape(N, 7), gtol, "d/d delta (apply backward)")
+    return pl, zf, o
+
+
+def _load_deformation(field, sd):
+    """Strict load of the reference module's gs_deformation_field.* state into DeformationField.mlp."""
+    own = {k[len("gs_deformation_field."):]: torch.as_tensor(v) for k, v in sd.items() if k.startswith("gs_deformation_field.")}
+    missing = field.mlp.load_state_dict(own, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", EMBED, ids=[os.path.basename(p)[:-4] for p in EMBED])
+def test_kernels_match_the_reference_module_fixture(path):
+    """f2, f3, a14, a16 kernel by kernel on the reference's own intermediates, then a14 -> a15 -> a16 as one piece
+    (DeformationField with the reference's weights): next.* and the gradients of every MLP parameter and of point_latent."""
+    from manigaussian_amd.deform import DeformationField
+    dev = _dev()
+    z = np.load(path)
+    c = _case(z)
+    ref = types.SimpleNamespace(
+        inputs={k[3:]: z[k] for k in z.files if k.startswith("in_")}, out={k[4:]: z[k] for k in z.files if k.startswith("out_")},
+        next={k[5:]: z[k] for k in z.files if k.startswith("next_")}, probe={k[6:]: z[k] for k in z.files if k.startswith("probe_")},
+        cot={k[4:]: z[k] for k in z.files if k.startswith("cot_")}, grad={k[5:]: z[k] for k in z.files if k.startswith("grad_")})
+    pl, zf, o = _check_kernels_against(ref, c["semantic"], dev)
+    field = DeformationField(use_action=c["use_action"], use_semantic_feature=c["semantic"], d_hidden=c["d_hidden"]).to(dev)
+    _load_deformation(field, {k[3:]: z[k] for k in z.files if k.startswith("sd_")})
+    field = field.to(dev)
+    pl2 = pl.detach().clone().requires_grad_(True)
+    nxt = field(pl2, zf, o["xyz_maps"][0], o["sh_maps"][0], o["rot_maps"][0], o["scale_maps"][0], o["opacity_maps"][0],
+                feature=o["feature_maps"][0], action=torch.as_tensor(z["in_action"]).to(dev) if c["use_action"] else None)
+    _close(nxt["xyz"], z["next_xyz_maps"][0], 1e-5, "DeformationField next.xyz")
+    _close(nxt["rot"], z["next_rot_maps"][0], 1e-5, "DeformationField next.rot")
+    ((nxt["xyz"] * torch.as_tensor(z["cot_next_xyz_maps"][0]).to(dev)).sum() +
+     (nxt["rot"] * torch.as_tensor(z["cot_next_rot_maps"][0]).to(dev)).sum()).backward()
+    for n_, p in field.mlp.named_parameters():
+        _close(p.grad, z["grad_param:gs_deformation_field." + n_], 1e-4, "grad " + n_)
+    _close(pl2.grad, z["grad_dyna_input"][:, :128], 1e-4, "grad point_latent through the deformation field")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantic", [False, True], ids=["action_d70", "semantic_d73"])
+def test_kernels_match_the_live_reference_module_at_production_size(semantic):
+    """The same, live: GeneralizableGSEmbedNet at conf/method/ManiGaussian_BC.yaml's sizes (d_hidden 512, 16 384 points, a
+    20^3 x 128 volume) executed on this GPU, every kernel fed the module's own intermediates."""
+    _need_reference()
+    dev = _dev()
+    net = ref_embed.build_net(512, use_action=True, semantic=semantic, seed=3, device=dev)
+    data = ref_embed.make_inputs(16384, D=20, seed=4, device=dev, use_action=True)
+    r = ref_embed.run(net, data)
+    cpu = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items() if torch.is_tensor(v)}  # noqa: E731
+    ref = types.SimpleNamespace(inputs=cpu(data), out=cpu({k: r.data[k] for k in ref_embed.OUT_KEYS}), next=cpu(r.data["next"]),
+                                probe=cpu(r.probe), cot=cpu(r.cot), grad=cpu({k: v for k, v in r.grad.items() if not k.startswith("param:")}))
+    _check_kernels_against(ref, semantic, dev, tol=2e-5, gtol=2e-4)
+
+
+# ------------------------------------------------------------------ GPU: the whole dynamic step (configs[3] / configs[4])
+
+def _views(V, W, H, dev):
+    from manigaussian_amd import GaussianRasterizationSettings
+    from manigaussian_amd import synthetic as syn
+    cams = syn.circle_cameras(max(V, 4), W, H, negative_focal=True)[:V]
+    kws = [syn.camera_settings_kwargs(c, 1, True, bg=(0.0, 0.0, 0.0)) for c in cams]
+    sets = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, bg=(0.0, 0.0, 0.0), device=dev)) for c in cams]
+    return kws, sets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [dict(N=16384, F=3, V=2, W=128), dict(N=16384, F=32, V=4, W=128), dict(N=100000, F=32, V=4, W=128)],
+                         ids=["manigaussian_16k_f3_2views", "16k_f32_4views", "configs3_100k_f32_4views"])
+def test_dynamic_step_matches_reference(case):
+    """One training step of the dynamic scene, end to end, reference against product (what `bench.py --config c4 / c5` times):
+
+      reference:  GeneralizableGSEmbedNet.forward (models_embed.py, unmodified, d_hidden 512) -> data['next'] ->
+                  V runs of the REFERENCE's rasterizer kernels (oracle/_ref, fwd + bwd) under the step's loss
+                  l2(rgb) + 0.01 l2(feature) -> the per-Gaussian gradients summed over the views -> torch backward through
+                  the reference module: gradients of every gs_deformation_field parameter and of point_latent;
+      product:    DeformationField (the reference's weights, strict load; HIP assembly -> GEMMs + fused passes -> HIP apply) fed
+                  the module's own current-frame maps -> ONE GaussianRasterizerBatch call (V views) -> the same loss ->
+                  autograd.
+
+    Images per view <= 2e-5 away from threshold-fragile pixels (REF_FRAGILE_TOL on those), radii bit-exact, every gradient
+    <= 1e-3 of its tensor's max."""
+    import util
+    from oracle import oracle_b, ref_cuda
+    from manigaussian_amd import GaussianRasterizerBatch
+    from manigaussian_amd.deform import DeformationField
+    _need_reference()
+    N, F, V, W = case["N"], case["F"], case["V"], case["W"]
+    if not ref_cuda.available(F):
+        pytest.skip("oracle/_ref/libmgs_ref*.so not built (needs /root/reference at build time)")
+    dev = _dev()
+    net = ref_embed.build_net(512, use_action=True, semantic=False, seed=5, device=dev)
+    data = ref_embed.make_inputs(N, D=16, seed=6, device=dev, use_action=True)
+    r = ref_embed.run(net, data, cotangents=False)
+    nxt = r.data["next"]
+    g = torch.Generator().manual_seed(8)
+    if F == 3:   # ManiGaussian's own 3-channel semantic feature, L2-normalised as render() does (gaussian_renderer/__init__.py:66-68)
+        fm = nxt["feature_maps"][0].detach()
+        lang = (fm / (fm.norm(dim=-1, keepdim=True) + 1e-12)).contiguous()
+    else:        # LangSplat-style 32-channel language feature (BASELINE configs[2]-[4]): a per-Gaussian input, unit norm
+        lang = torch.nn.functional.normalize(torch.randn(N, F, generator=g), dim=-1).to(dev)
+    kws, sets = _views(V, W, W, dev)
+    tgt_c, tgt_f = torch.rand(V, 3, W, W, generator=g), torch.randn(V, F, W, W, generator=g) * 0.3
+    n_c, n_f = float(tgt_c.numel()), float(tgt_f.numel())
+
+    # ---- reference side: its kernels per view, the loss's cotangents formed from ITS images
+    cpu = lambda t: t.detach().cpu()  # noqa: E731
+    sc = dict(means3D=cpu(nxt["xyz_maps"][0]), opacities=cpu(nxt["opacity_maps"][0]), shs=cpu(nxt["sh_maps"][0]),
+              scales=cpu(nxt["scale_maps"][0]), rotations=cpu(nxt["rot_maps"][0]), language_feature=cpu(lang))
+    ref_imgs, g_xyz, g_rot, frag_px = [], torch.zeros(N, 3), torch.zeros(N, 4), []
+    for v in range(V):
+        st = types.SimpleNamespace(**kws[v])
+        zero = torch.zeros(3, W, W), torch.zeros(F, W, W)
+        c, f, radii, _, _ = ref_cuda.forward_backward(sc["means3D"], sc["opacities"], st, zero[0], zero[1], shs=sc["shs"],
+                                                      language_feature=sc["language_feature"], scales=sc["scales"],
+                                                      rotations=sc["rotations"])
+        dC, dF = 2.0 * (c - tgt_c[v]) / n_c, 0.01 * 2.0 * (f - tgt_f[v]) / n_f
+        c2, f2, radii2, gr, _ = ref_cuda.forward_backward(sc["means3D"], sc["opacities"], st, dC, dF, shs=sc["shs"],
+                                                          language_feature=sc["language_feature"], scales=sc["scales"],
+                                                          rotations=sc["rotations"])
+        assert torch.equal(c2, c) and torch.equal(radii2, radii)
+        ref_imgs.append((c, f, radii))
+        g_xyz += gr["means3D"]
+        g_rot += gr["rotations"]
+        state = oracle_b.forward(sc["means3D"], sc["opacities"], st, shs=sc["shs"], language_feature=sc["language_feature"],
+                                 scales=sc["scales"], rotations=sc["rotations"])[3]
+        frag_px.append(oracle_b.fragile_mask(state))
+        del state
+    net.zero_grad(set_to_none=True)
+    torch.autograd.backward([nxt["xyz_maps"], nxt["rot_maps"]], [g_xyz.to(dev)[None], g_rot.to(dev)[None]])
+    ref_grads = {n_: p.grad.detach().cpu() for n_, p in net.gs_deformation_field.named_parameters()}
+    ref_g_latent = r.probe["point_latent"].grad.detach().cpu().reshape(N, 128)
+    assert all(v.abs().max() > 0 for v in ref_grads.values()) and ref_g_latent.abs().max() > 0
+
+    # ---- product side
+    field = DeformationField(use_action=True, use_semantic_feature=False, d_hidden=512).to(dev)
+    _load_deformation(field, {k: v.detach().cpu() for k, v in net.state_dict().items()})
+    field = field.to(dev)
+    cur = {k: r.data[k][0].detach() for k in ref_embed.OUT_KEYS}
+    pl = r.probe["point_latent"].detach().reshape(N, 128).clone().requires_grad_(True)
+    zf = r.probe["latent_in"][:, 128:].detach().contiguous()
+    out = field(pl, zf, cur["xyz_maps"], cur["sh_maps"], cur["rot_maps"], cur["scale_maps"], cur["opacity_maps"],
+                feature=cur["feature_maps"], action=data["action"])
+    _close(out["xyz"], nxt["xyz_maps"][0].cpu(), 1e-5, "next.xyz")
+    _close(out["rot"], nxt["rot_maps"][0].cpu(), 1e-5, "next.rot")
+    color, feat, radii = GaussianRasterizerBatch(sets)(out["xyz"], None, out["opacity"], shs=out["sh"],
+                                                       language_feature_precomp=lang, scales=out["scale"], rotations=out["rot"])
+    loss = ((color - tgt_c.to(dev)) ** 2).mean() + 0.01 * ((feat - tgt_f.to(dev)) ** 2).mean()
+    # .mean() over [V, ...]: the reference side applied the same normalisation per view (n_c, n_f count all V views)
+    params = list(field.mlp.parameters())
+    grads = torch.autograd.grad(loss, params + [pl])
+    torch.cuda.synchronize()
+    stats = {}
+    for v in range(V):
+        c, f, rd = ref_imgs[v]
+        assert torch.equal(radii[v].cpu(), rd), f"radii, view {v}"
+        for nm, a, b in (("color", color[v], c), ("feature", feat[v], f)):
+            e = (a.detach().cpu() - b).abs().max(0)[0]
+            ok = ~frag_px[v]
+            stats[f"{nm}{v}"] = float(e.max())
+            assert e[ok].max().item() <= 2e-5, (nm, v, e[ok].max().item())
+            assert e.max().item() <= util.REF_FRAGILE_TOL and int((e > 1e-4).sum()) <= util.REF_MAX_PIXELS_ABOVE_CONTRACT, (nm, v)
+    for (n_, _), g_ in zip(field.mlp.named_parameters(), grads[:-1]):
+        ref_g = ref_grads[n_]
+        err = (g_.cpu() - ref_g).abs().max().item()
+        stats["grad_" + n_] = err / ref_g.abs().max().item()
+        assert err <= 1e-3 * ref_g.abs().max().item() + 1e-9, (n_, err, ref_g.abs().max().item())
+    err = (grads[-1].cpu() - ref_g_latent).abs().max().item()
+    stats["grad_point_latent"] = err / ref_g_latent.abs().max().item()
+    assert err <= 1e-3 * ref_g_latent.abs().max().item() + 1e-9, ("point_latent", err)
+    util.report("dynamic_step " + repr(case), **stats)
