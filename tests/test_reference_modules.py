@@ -286,8 +286,14 @@ def test_dynamic_step_matches_reference(case):
                   the module's own current-frame maps -> ONE GaussianRasterizerBatch call (V views) -> the same loss ->
                   autograd.
 
-    Images per view <= 2e-5 away from threshold-fragile pixels (REF_FRAGILE_TOL on those), radii bit-exact, every gradient
-    <= 1e-3 of its tensor's max."""
+    Two comparisons, because the two chains do not hand the rasterizer bit-identical Gaussians (the product's MLP adds its
+    biases in another order: next.xyz / next.rot agree to ~1e-6 relative, i.e. ~1e-4 px on screen):
+      (B) IDENTICAL SETS -- the product's batched rasterizer on the REFERENCE's next.* against the reference kernels, at the
+          strict bounds of test_live_reference (2e-5 off threshold-fragile pixels, REF_FRAGILE_TOL on those, a handful of
+          pixels above 1e-4 at most, radii bit-exact, per-Gaussian gradients 1e-3 of the max);
+      (C) END TO END -- the product's own chain against the reference's, at the north star's contract: images 1e-4 away from
+          pixels with a pair within 1e-3 (relative) of a hard threshold -- the sensitivity of alpha to a 1e-4 px shift --,
+          the flipped-pair bound on those, and EVERY gradient (all MLP parameters, point_latent) within 1e-3 of its max."""
     import util
     from oracle import oracle_b, ref_cuda
     from manigaussian_amd import GaussianRasterizerBatch
@@ -315,7 +321,8 @@ def test_dynamic_step_matches_reference(case):
     cpu = lambda t: t.detach().cpu()  # noqa: E731
     sc = dict(means3D=cpu(nxt["xyz_maps"][0]), opacities=cpu(nxt["opacity_maps"][0]), shs=cpu(nxt["sh_maps"][0]),
               scales=cpu(nxt["scale_maps"][0]), rotations=cpu(nxt["rot_maps"][0]), language_feature=cpu(lang))
-    ref_imgs, g_xyz, g_rot, frag_px = [], torch.zeros(N, 3), torch.zeros(N, 4), []
+    ref_imgs, cots, g_xyz, g_rot, frag_px, frag_px_wide = [], [], torch.zeros(N, 3), torch.zeros(N, 4), [], []
+    frag_g = torch.zeros(N, dtype=torch.bool)
     for v in range(V):
         st = types.SimpleNamespace(**kws[v])
         zero = torch.zeros(3, W, W), torch.zeros(F, W, W)
@@ -328,19 +335,50 @@ def test_dynamic_step_matches_reference(case):
                                                           rotations=sc["rotations"])
         assert torch.equal(c2, c) and torch.equal(radii2, radii)
         ref_imgs.append((c, f, radii))
+        cots.append((dC, dF))
         g_xyz += gr["means3D"]
         g_rot += gr["rotations"]
         state = oracle_b.forward(sc["means3D"], sc["opacities"], st, shs=sc["shs"], language_feature=sc["language_feature"],
                                  scales=sc["scales"], rotations=sc["rotations"])[3]
         frag_px.append(oracle_b.fragile_mask(state))
+        frag_px_wide.append(oracle_b.fragile_mask(state, 1e-3))
+        frag_g |= oracle_b.fragile_gaussians(state)
         del state
     net.zero_grad(set_to_none=True)
     torch.autograd.backward([nxt["xyz_maps"], nxt["rot_maps"]], [g_xyz.to(dev)[None], g_rot.to(dev)[None]])
     ref_grads = {n_: p.grad.detach().cpu() for n_, p in net.gs_deformation_field.named_parameters()}
     ref_g_latent = r.probe["point_latent"].grad.detach().cpu().reshape(N, 128)
     assert all(v.abs().max() > 0 for v in ref_grads.values()) and ref_g_latent.abs().max() > 0
+    stats = {}
 
-    # ---- product side
+    def compare_images(color, feat, radii, masks, tol_clean, tol_fragile, max_above, tag):
+        for v in range(V):
+            c, f, rd = ref_imgs[v]
+            assert torch.equal(radii[v].cpu(), rd), f"{tag}: radii, view {v}"
+            for nm, a, b in (("color", color[v], c), ("feature", feat[v], f)):
+                e = (a.detach().cpu() - b).abs().max(0)[0]
+                ok = ~masks[v]
+                stats[f"{tag}_{nm}{v}"] = dict(max=float(e.max()), max_clean=float(e[ok].max()), above_1e_4=int((e > 1e-4).sum()),
+                                               marked=float(masks[v].float().mean()))
+                assert e[ok].max().item() <= tol_clean, (tag, nm, v, e[ok].max().item())
+                assert e.max().item() <= tol_fragile, (tag, nm, v, e.max().item())
+                assert int((e > 1e-4).sum()) <= max_above, (tag, nm, v, int((e > 1e-4).sum()))
+
+    # ---- (B) identical sets: the product's batched rasterizer on the reference's next.*
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    cB, fB, rB = GaussianRasterizerBatch(sets)(leaves["means3D"], None, leaves["opacities"], shs=leaves["shs"],
+                                               language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                                               rotations=leaves["rotations"])
+    torch.autograd.backward([cB, fB], [torch.stack([c_ for c_, _ in cots]).to(dev), torch.stack([f_ for _, f_ in cots]).to(dev)])
+    torch.cuda.synchronize()
+    compare_images(cB, fB, rB, frag_px, 2e-5, util.REF_FRAGILE_TOL, util.REF_MAX_PIXELS_ABOVE_CONTRACT, "identical_sets")
+    for nm, got, ref_g in (("means3D", leaves["means3D"].grad.cpu(), g_xyz), ("rotations", leaves["rotations"].grad.cpu(), g_rot)):
+        d = (got - ref_g).abs().max(1)[0]
+        mag = ref_g.abs().max().item()
+        stats["identical_sets_grad_" + nm] = d.max().item() / mag
+        assert d[~frag_g].max().item() <= 1e-3 * mag + 1e-12 and d.max().item() <= util.REF_FRAGILE_GRAD_TOL * mag + 1e-12, nm
+
+    # ---- (C) end to end: the product's own chain
     field = DeformationField(use_action=True, use_semantic_feature=False, d_hidden=512).to(dev)
     _load_deformation(field, {k: v.detach().cpu() for k, v in net.state_dict().items()})
     field = field.to(dev)
@@ -353,27 +391,33 @@ def test_dynamic_step_matches_reference(case):
     _close(out["rot"], nxt["rot_maps"][0].cpu(), 1e-5, "next.rot")
     color, feat, radii = GaussianRasterizerBatch(sets)(out["xyz"], None, out["opacity"], shs=out["sh"],
                                                        language_feature_precomp=lang, scales=out["scale"], rotations=out["rot"])
-    loss = ((color - tgt_c.to(dev)) ** 2).mean() + 0.01 * ((feat - tgt_f.to(dev)) ** 2).mean()
     # .mean() over [V, ...]: the reference side applied the same normalisation per view (n_c, n_f count all V views)
+    loss = ((color - tgt_c.to(dev)) ** 2).mean() + 0.01 * ((feat - tgt_f.to(dev)) ** 2).mean()
     params = list(field.mlp.parameters())
     grads = torch.autograd.grad(loss, params + [pl])
     torch.cuda.synchronize()
-    stats = {}
+    stats["end_to_end_next_xyz_rel"] = ((out["xyz"].cpu() - nxt["xyz_maps"][0].cpu()).abs().max() / nxt["xyz_maps"].abs().max().cpu()).item()
+    # radii: ceil(3 sqrt(lambda)) of a covariance built from a rotation that differs in its last bits may sit on the other side
+    # of an integer for a few Gaussians out of 10^5 -- counted, not asserted bit for bit, in the end-to-end comparison
+    flips = sum(int((radii[v].cpu() != ref_imgs[v][2]).sum()) for v in range(V))
+    stats["end_to_end_radii_flips"] = flips
+    assert flips <= max(2, N * V // 20000), flips
     for v in range(V):
         c, f, rd = ref_imgs[v]
-        assert torch.equal(radii[v].cpu(), rd), f"radii, view {v}"
         for nm, a, b in (("color", color[v], c), ("feature", feat[v], f)):
             e = (a.detach().cpu() - b).abs().max(0)[0]
-            ok = ~frag_px[v]
-            stats[f"{nm}{v}"] = float(e.max())
-            assert e[ok].max().item() <= 2e-5, (nm, v, e[ok].max().item())
-            assert e.max().item() <= util.REF_FRAGILE_TOL and int((e > 1e-4).sum()) <= util.REF_MAX_PIXELS_ABOVE_CONTRACT, (nm, v)
+            ok = ~frag_px_wide[v]
+            stats[f"end_to_end_{nm}{v}"] = dict(max=float(e.max()), max_clean=float(e[ok].max()), above_1e_4=int((e > 1e-4).sum()),
+                                                marked=float(frag_px_wide[v].float().mean()))
+            assert e[ok].max().item() <= 1e-4, ("end to end", nm, v, e[ok].max().item())
+            assert e.max().item() <= util.FRAGILE_TOL, ("end to end", nm, v, e.max().item())
+            assert int((e > 1e-4).sum()) <= max(util.REF_MAX_PIXELS_ABOVE_CONTRACT, W * W // 500), ("end to end", nm, v)
     for (n_, _), g_ in zip(field.mlp.named_parameters(), grads[:-1]):
         ref_g = ref_grads[n_]
         err = (g_.cpu() - ref_g).abs().max().item()
-        stats["grad_" + n_] = err / ref_g.abs().max().item()
+        stats["end_to_end_grad_" + n_] = err / ref_g.abs().max().item()
         assert err <= 1e-3 * ref_g.abs().max().item() + 1e-9, (n_, err, ref_g.abs().max().item())
     err = (grads[-1].cpu() - ref_g_latent).abs().max().item()
-    stats["grad_point_latent"] = err / ref_g_latent.abs().max().item()
+    stats["end_to_end_grad_point_latent"] = err / ref_g_latent.abs().max().item()
     assert err <= 1e-3 * ref_g_latent.abs().max().item() + 1e-9, ("point_latent", err)
     util.report("dynamic_step " + repr(case), **stats)
