@@ -537,7 +537,7 @@ def main():
 
         roof = roof_block("K8 render backward (gm_bwd_kernel)", "gm_bwd_kernel", bwd_avg_ms, bwd_n, bytes_k8)
         bytes_k7 = R * (40 + 4 * F) + npix * (4 * (3 + F) + 8)
-        roof_fwd = roof_block("K7 render forward (coop_fwd_dense_kernel)", "coop_fwd_dense_kernel",
+        roof_fwd = roof_block("K7 render forward (coop_fwd_pairs_kernel)", "coop_fwd_pairs_kernel",
                               stages.get("render_fwd", 0.0), min(steps, 20), bytes_k7)
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",

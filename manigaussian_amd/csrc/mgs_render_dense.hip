@@ -24,44 +24,57 @@ __device__ unsigned long long g_trace[512 * 16 * TRACE_EVENTS];
       g_trace[((size_t)blockIdx.x * 16 + w) * TRACE_EVENTS + (ev)] = __builtin_amdgcn_s_memtime();         \
   } while (0)
 
-// CHS = survivors per chunk = per wave and round (64: two full 32-lane groups for the backward; 32: one).
+// Blend: wave PAIRS, lane = (pixel of a half block, entry parity).
 //
-// Blend.  The phase timeline (scripts/trace_fwd.py) showed the LDS-staged broadcast rows of coop_fwd64_kernel to be the
-// bottleneck of phase B: nine ds_read_b128 per entry and wave cost 72 LDS cycles each whatever the broadcast, times the
-// waves of the CU.  Here no row goes through LDS:
-//   * F >= 16: the feature contraction  C[pixel][ch] += w[pixel][entry] * feat[entry][ch]  runs on the matrix cores in
-//     exact fp32 (v_mfma_f32_32x32x2_f32 = an fmaf chain).  The B operand is the feature row in its natural layout (lane
-//     (k, ch) loads feat[entry 2kk + k][ch]: one coalesced 128-B row per entry, a ring of four pairs in flight); the A operand is
-//     the blend weight the pixel lanes just computed: for an entry pair (j, j+1) ONE v_permlane32_swap turns
-//     (w_j, w_j+1) into the operands of the two pixel tiles (pixels 0..31 / 32..63).  Accumulators leave through one LDS
-//     transposition per chunk.
-//   * the three colour channels (and every channel when F < 16) are FMAs against v_readlane broadcasts of the row
-//     registers of the lane that owns the entry.
+// Round 2's kernel gave a whole wave to a chunk with lane = pixel and walked the chunk's 64 entries one by one, every
+// entry's record broadcast to the 64 pixel lanes with six v_readlane, and evaluated every alpha twice (phase A for the
+// transmittance product, phase B for the blend): 97 VALU instructions per entry and wave (6 200 per chunk), ~7 live waves of
+// 16 at BASELINE configs[2] -- latency-bound at 14-22 % VALU issue (profiles/r02_sq_counters.json).  Here TWO waves share
+// a chunk, one per half block (8 x 4 pixels), and a lane is (pixel p, entry parity k): step s evaluates entries 2s and
+// 2s + 1 for 32 pixels -- 64 distinct (pixel, entry) pairs per instruction, no broadcast:
+//   * the chunk's records are staged once in the wave's LDS; a lane reads its entry's record with two broadcast
+//     ds_reads (32 lanes per address);
+//   * phase A keeps its 32 alphas per lane in registers, so phase B evaluates no exp at all;
+//   * the serial per-pixel chain (forward.cu:357-380) is 32 steps of two entries: ONE v_permlane32_swap hands each half
+//     the other parity's alpha, both lanes of a pixel then run the identical chain;
+//   * lane (p, k) IS the A-operand layout of v_mfma_f32_32x32x2_f32 (row = pixel, k = entry of the pair) and lane (ch, k)
+//     the B layout: one MFMA per step and 32 channels, no operand shuffles; the accumulators leave through one LDS
+//     transposition per chunk;
+//   * twice the live waves per block, each with a quarter of the instructions.
+// A pair blends up to NS = 2 chunks per round (chunks pr and pr + NW/2), so a round still covers NW chunks: blocks whose
+// pixels need more than NW/2 chunks (15 % of them at configs[2]) do not pay a second fill / barrier round.
+// Per-pixel results are those of the reference's walk: same alpha expression, same test order, same sequential T chain.
 // TWO: two workgroups of this kernel share a CU (8 waves, <= 128 registers, <= 80 KB of LDS each)
 template <int F, bool FAST, bool EXACT, int NW, int CHS, bool TWO>
 __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1)
-coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       float* __restrict__ T_end, float* __restrict__ T_mid,
                       uint32_t* __restrict__ last_pos, float* __restrict__ partial, uint32_t* __restrict__ surv,
                       size_t surv_stride, uint2* __restrict__ nsurv, float* __restrict__ final_T,
                       uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat,
                       uint32_t* __restrict__ round_base, uint32_t pool, uint32_t* __restrict__ flags, int nblocks,
                       uint64_t* host_status, uint32_t status_tag) {
-  static_assert(CHS == 32 || CHS == 64, "a chunk is one or two 32-lane groups of the Gaussian-major backward");
+  static_assert(CHS == 64, "a chunk is two 32-lane groups of the Gaussian-major backward");
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int NCH = F + 3;
   constexpr bool MF = F >= 16;               // feature channels on the matrix cores
   constexpr int NT = MF ? (F + 31) / 32 : 0; // 32-channel tiles
-  constexpr int NV = MF ? 3 : NCH;           // channels blended on the VALU: [features (F < 16)], r, g, b
-  constexpr int NKK = CHS / 2;               // entry pairs per chunk
-  constexpr int TRS = 65;                    // row stride of the transposition buffer (odd: conflict-free)
-  constexpr int NOWN = (NCH + NW - 1) / NW;  // image channels owned by one wave
+  constexpr int NVF = MF ? 0 : F;            // feature channels blended on the VALU
+  constexpr int NP = NW / 2;                 // wave pairs
+  constexpr int NS = 2;                      // chunks a pair blends per round
+  constexpr int NSTEP = CHS / 2;             // steps per chunk: two entries each
+  constexpr int TRS = 33;                    // row stride of the transposition buffer [channel][32 pixels] (odd: conflict-free)
+  constexpr int NOWN = (NCH + NW - 1) / NW;  // image channels owned by one wave (final sum)
   constexpr uint32_t ROUND = NW * CHS;       // survivors blended per round
   constexpr uint32_t FSTEP = NW * 64;        // entries examined per fill sub-step (one per thread)
   constexpr int FILLK = 3;                   // sub-steps per fill step (all loads in flight together): at BASELINE configs[2]
                                              // a block needs ~2400 list entries for its first 1024 survivors -- one step, not two
   __shared__ float trs[MF ? NW * NT * 32 * TRS : 1];  // per wave: [channel][pixel] hand-over of the MFMA accumulators
-  __shared__ float Tp[2][NW][64];            // per-chunk transmittance products, double buffered over rounds
+  __shared__ float4 recA[NW][CHS];           // per wave, the chunk under evaluation: {x, y, conic.x, conic.y}
+  __shared__ float2 recB[NW][CHS];           //                                       {conic.z, opacity (0: no entry)}
+  __shared__ float4 rowq[NW][NS][CHS];       // per wave and chunk slot, for the blend: {r, g, b, Gaussian (bits)}
+  __shared__ float rowf[NVF > 0 ? NW * NS * CHS * NVF : 1];  // ... and the feature row when it is blended on the VALU
+  __shared__ float Tp[2][NW][64];            // per-chunk transmittance products [chunk of the round][pixel], double buffered
   __shared__ float red_Tf[64];
   __shared__ uint32_t red_vis[64];
   __shared__ uint32_t cnt[2][FILLK * NW];    // survivors per (sub-step, wave) of a fill step, double buffered
@@ -70,17 +83,23 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   __shared__ uint32_t rb_hist[RBH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: tell the compiler (scalar branches)
+  const int pr = w >> 1, hh = w & 1;         // my pair; my half block (pixel rows 4 hh .. 4 hh + 3)
+  const int k = lane >> 5, pl = lane & 31;   // my entry parity; my pixel inside the half block
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;  // padding blocks of the grid (not counted in nblocks)
-  const PixBlk p = pix_blk(r, tile, sub, lane);
+  const PixBlk p = pix_blk(r, tile, sub, lane);            // lane = pixel: the fill's cull and the final image sum
+  const int pixq = 32 * hh + pl;                           // my pixel in the blend phases
+  const PixBlk pq = pix_blk(r, tile, sub, pixq);
+  const int pixx = 32 * (hh ^ k) + pl;                     // the pixel whose round-to-round transmittance this lane tracks:
+  const bool insidex = pix_blk(r, tile, sub, pixx).inside; // k = 0 lanes their own, k = 1 lanes the other half's (64 in all)
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
   uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);  // entry of round k: my_rounds[4 * k]
   bool overflow = false;   // the chunk pool ran out (workgroup-uniform): stop, the host will see the flag
   uint32_t* my_surv = surv + (size_t)sub * surv_stride + rng.x;  // this block's compacted list of instance ids: at most len entries
 
-  float Tround = 1.0f;
+  float Tround = 1.0f;     // transmittance of pixel pixx entering the round
   uint32_t my_vis = 0;
   float my_Tf = 1.0f;
   MGS_TRACE(0);
@@ -108,21 +127,21 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       {
         float4 a0[FILLK], a1[FILLK];
 #pragma unroll
-        for (int k = 0; k < FILLK; k++) {
-          const uint32_t e = next + (uint32_t)k * FSTEP + (uint32_t)tid;
-          idd[k] = e < rng.y ? point_list[e] : 0xffffffffu;
+        for (int kf = 0; kf < FILLK; kf++) {
+          const uint32_t e = next + (uint32_t)kf * FSTEP + (uint32_t)tid;
+          idd[kf] = e < rng.y ? point_list[e] : 0xffffffffu;
         }
 #pragma unroll
-        for (int k = 0; k < FILLK; k++) {
-          a0[k] = make_float4(0, 0, 0, 0); a1[k] = make_float4(0, 0, -1.f, -1.f);
-          if (idd[k] != 0xffffffffu) { a0[k] = r.rec[2 * (size_t)idd[k]]; a1[k] = r.rec[2 * (size_t)idd[k] + 1]; }
+        for (int kf = 0; kf < FILLK; kf++) {
+          a0[kf] = make_float4(0, 0, 0, 0); a1[kf] = make_float4(0, 0, -1.f, -1.f);
+          if (idd[kf] != 0xffffffffu) { a0[kf] = r.rec[2 * (size_t)idd[kf]]; a1[kf] = r.rec[2 * (size_t)idd[kf] + 1]; }
         }
 #pragma unroll
-        for (int k = 0; k < FILLK; k++) {
-          const bool sk = idd[k] != 0xffffffffu && cull_ok<EXACT>(a0[k], a1[k], p);
+        for (int kf = 0; kf < FILLK; kf++) {
+          const bool sk = idd[kf] != 0xffffffffu && cull_ok<EXACT>(a0[kf], a1[kf], p);
           const unsigned long long sm = ballot(sk);
-          rk[k] = sk ? (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1ull)) : 0xffffffffu;
-          if (lane == 0) cnt[fill & 1][k * NW + w] = (uint32_t)__builtin_popcountll(sm);
+          rk[kf] = sk ? (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1ull)) : 0xffffffffu;
+          if (lane == 0) cnt[fill & 1][kf * NW + w] = (uint32_t)__builtin_popcountll(sm);
         }
       }
       __syncthreads();
@@ -136,9 +155,9 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       }
       const uint32_t total = bcast_lane_u32(incl, 63);
 #pragma unroll
-      for (int k = 0; k < FILLK; k++) {
-        const uint32_t base = bcast_lane_u32(incl - v, k * NW + w);
-        if (rk[k] != 0xffffffffu) my_surv[qtail + base + rk[k]] = idd[k];
+      for (int kf = 0; kf < FILLK; kf++) {
+        const uint32_t base = bcast_lane_u32(incl - v, kf * NW + w);
+        if (rk[kf] != 0xffffffffu) my_surv[qtail + base + rk[kf]] = idd[kf];
       }
       qtail += total;
       next += FILLK * FSTEP;
@@ -157,189 +176,227 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     uint32_t nchunk = exhausted ? (avail + CHS - 1) / CHS : avail / CHS;
     nchunk = min(nchunk, (uint32_t)NW);
     if (nchunk == 0) break;
-    const uint32_t c = cbase + (uint32_t)w;
-    const bool has = (uint32_t)w < nchunk;
-    const uint32_t n_my = has ? min((uint32_t)CHS, avail - (uint32_t)w * CHS) : 0u;  // survivors of my chunk
-    const bool valid = (uint32_t)lane < n_my;
-    // ---- my chunk: lane e holds entry e's record and its VALU-blended row; the feature rows go to the B operands ----
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
-    float rowv[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) rowv[i] = 0.f;
-    uint32_t gidl = 0;  // Gaussian (feature row) of my entry
-    if (valid) {
-      const uint32_t id = my_surv[qhead + (uint32_t)w * CHS + (uint32_t)lane];
-      g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
-      const uint32_t gid = gauss_of(r, id);
-      gidl = gid;
-      const uint32_t cid = r.colors_per_view ? id : gid;  // colour row: per view when it comes from SH
-      if constexpr (!MF && F > 0) {
-        if (use_feat) {
-#pragma unroll
-          for (int i = 0; i < F; i++) rowv[i] = r.feats[(size_t)gid * F + i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) rowv[NV - 3 + i] = r.colors[(size_t)cid * 3 + i];
-    }
-    // B operand of entry pair kk: lane (k = lane >> 5, ch = lane & 31) loads feat[entry 2kk + k][32 t + ch].  A ring of BD
-    // pairs is kept in flight (loaded BD pairs ahead of their use): the whole chunk's operands would not fit the registers.
-    constexpr int BD = 4;
-    auto load_B = [&](float (&B)[NT > 0 ? NT : 1][BD], int kk) {
-      const uint32_t gA = bcast_lane_u32(gidl, 2 * kk), gB = bcast_lane_u32(gidl, 2 * kk + 1);
-      const uint32_t ent = 2u * kk + (uint32_t)(lane >> 5);
-      const uint32_t gide = lane < 32 ? gA : gB;
-#pragma unroll
-      for (int t = 0; t < (NT > 0 ? NT : 1); t++) {
-        const int ch = 32 * t + (lane & 31);
-        B[t][kk % BD] = (MF && ent < n_my && ch < F && use_feat) ? r.feats[(size_t)gide * F + ch] : 0.f;
-      }
-    };
-    float Bq[NT > 0 ? NT : 1][BD];
-    if constexpr (MF) {
-#pragma unroll
-      for (int kk = 0; kk < BD; kk++) load_B(Bq, kk);
-    }
-    MGS_TRACE(3 + 8 * round);
-    // alpha of entry j for my pixel with the reference's two skip tests folded in (forward.cu:345-356): 0 = skipped.
-    // (1 - 0 = 1 exactly, so a skipped entry leaves every product bit for bit alone.)
-    auto alpha_of = [&](int j) -> float {
-      const float ex = bcast_lane(g0.x, j), ey = bcast_lane(g0.y, j);
-      const float cx = bcast_lane(g0.z, j), cy = bcast_lane(g0.w, j), cz = bcast_lane(g1.x, j);
-      const float op = bcast_lane(g1.y, j);
-      const float dx = ex - p.pxf, dy = ey - p.pyf;
-      const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-      const float alpha = fminf(0.99f, op * exp_<FAST>(power));
+
+    // ---- phase A: my pair's chunks pr and pr + NP: stage the records, alpha of (my pixel, my entries), the products ----
+    // alpha of entry 2s + k for pixel pixq with the reference's two skip tests folded in (forward.cu:345-356; 0 = skipped:
+    // 1 - 0 = 1 exactly, a skipped entry leaves every product alone), from the records staged in this wave's LDS
+    auto alpha_of = [&](int s) -> float {
+      const float4 A = recA[w][2 * s + k];
+      const float2 B = recB[w][2 * s + k];
+      const float dx = A.x - pq.pxf, dy = A.y - pq.pyf;
+      const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+      const float alpha = fminf(0.99f, B.y * exp_<FAST>(power));
       return ((power > 0.0f) || (alpha < 1.0f / 255.0f)) ? 0.f : alpha;
     };
-    // ---- phase A: transmittance product of this chunk (four independent alphas in flight, then the product chain) ----
-    float tp = 1.0f;
-    if (n_my == (uint32_t)CHS) {
+    float al[NSTEP];          // the alphas of my FIRST chunk stay in registers: its blend evaluates no exp.  (The second
+                              // chunk of a round -- blocks with more than NW/2 live chunks -- is staged last, so its records
+                              // are still in recA / recB when it is blended: its alphas are evaluated again there.)
+    uint32_t nmy[NS];         // survivors of my chunks
 #pragma unroll
-      for (int j = 0; j < CHS; j += 4) {
-        const float a0 = alpha_of(j), a1 = alpha_of(j + 1), a2 = alpha_of(j + 2), a3 = alpha_of(j + 3);
-        tp = tp * (1.0f - a0); tp = tp * (1.0f - a1); tp = tp * (1.0f - a2); tp = tp * (1.0f - a3);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < NS; q++) {
+      const uint32_t ci = (uint32_t)pr + (uint32_t)q * NP;
+      const bool hasq = ci < nchunk;  // wave-uniform
+      nmy[q] = hasq ? min((uint32_t)CHS, avail - ci * CHS) : 0u;
+      if (q == 0) {
+#pragma unroll
+        for (int s = 0; s < NSTEP; s++) al[s] = 0.f;
       }
-    } else {
-      for (uint32_t j = 0; j < n_my; j++) tp = tp * (1.0f - alpha_of((int)j));
+      float tp = 1.0f;
+      if (hasq) {
+        // lane e stages entry e of the chunk
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+        float4 rq = make_float4(0, 0, 0, __uint_as_float(0u));
+        float fv[NVF > 0 ? NVF : 1];
+#pragma unroll
+        for (int i = 0; i < (NVF > 0 ? NVF : 1); i++) fv[i] = 0.f;
+        const bool valid = (uint32_t)lane < nmy[q];
+        if (valid) {
+          const uint32_t id = my_surv[qhead + ci * CHS + (uint32_t)lane];
+          g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
+          const uint32_t gid = gauss_of(r, id);
+          const uint32_t cid = r.colors_per_view ? id : gid;  // colour row: per view when it comes from SH
+          rq = make_float4(r.colors[(size_t)cid * 3], r.colors[(size_t)cid * 3 + 1], r.colors[(size_t)cid * 3 + 2],
+                           __uint_as_float(gid));
+          if constexpr (NVF > 0) {
+            if (use_feat) {
+#pragma unroll
+              for (int i = 0; i < NVF; i++) fv[i] = r.feats[(size_t)gid * F + i];
+            }
+          }
+        }
+        wave_lds_sync();  // this wave's readers of recA / recB (the previous chunk's phase A) are done
+        recA[w][lane] = g0;
+        recB[w][lane] = make_float2(g1.x, valid ? g1.y : 0.f);  // opacity 0 => alpha 0 => skipped: no bounds test per step
+        rowq[w][q][lane] = rq;
+        if constexpr (NVF > 0) {
+#pragma unroll
+          for (int i = 0; i < NVF; i++) rowf[(((size_t)w * NS + q) * CHS + lane) * NVF + i] = fv[i];
+        }
+        wave_lds_sync();
+        if (q == 0) MGS_TRACE(3 + 8 * round);
+        // straight-line: no per-step branch (an entry past the chunk's end has opacity 0 => alpha 0), so that the
+        // compiler batches the LDS reads of several steps ahead of their use
+#pragma unroll
+        for (int s = 0; s < NSTEP; s++) {
+          const float a = alpha_of(s);
+          if (q == 0) al[s] = a;
+          tp = tp * (1.0f - a);
+        }
+        float t0 = tp, t1 = tp;
+        swap32(t0, t1);       // t0: the even entries' product, t1: the odd entries', in both lanes of the pixel
+        tp = t0 * t1;
+      }
+      if (k == 0) Tp[round & 1][ci][pixq] = tp;  // (1 for a chunk slot the round does not use)
     }
     MGS_TRACE(4 + 8 * round);
-    Tp[round & 1][w][lane] = tp;
     __syncthreads();
     MGS_TRACE(5 + 8 * round);
     const uint32_t rb = rbase[round & 1];
     if (rb + (uint32_t)NW > pool) { overflow = true; break; }  // uniform: every thread reads the same word
-    // ---- prefix in chunk order (identical arithmetic in every wave) ----
-    float T = Tround, Tnext = Tround;
+    // ---- prefix in chunk order (identical arithmetic in every wave): transmittance of pixel pixx entering my chunks ----
+    float Tin[NS], Tnext = Tround;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; w2++) {
-      const float t2 = Tp[round & 1][w2][lane];
-      T = (w2 < w) ? T * t2 : T;
+    for (int q = 0; q < NS; q++) Tin[q] = Tround;
+#pragma unroll
+    for (int c2 = 0; c2 < NW; c2++) {
+      const float t2 = Tp[round & 1][c2][pixx];
+#pragma unroll
+      for (int q = 0; q < NS; q++) Tin[q] = (c2 < pr + q * NP) ? Tin[q] * t2 : Tin[q];
       Tnext *= t2;
     }
-    // ---- phase B: blend this chunk ----
-    const bool live = has && p.inside && !(T < 0.0001f);
-    if (ballot(live) != 0) {
-      float C[NCH];
+    // ---- phase B: blend my chunks ----
 #pragma unroll
-      for (int i = 0; i < NCH; i++) C[i] = 0.f;
-      f32x16 acc[NT > 0 ? NT : 1][2];
+    for (int q = 0; q < NS; q++) {
+      const uint32_t ci = (uint32_t)pr + (uint32_t)q * NP;
+      const bool hasq = ci < nchunk;
+      // the k = 1 lanes tracked the other half's pixel: they take my pixel's transmittance from their k = 0 partner
+      const float Tpart = __uint_as_float(lane_xor<32>(__float_as_uint(Tin[q]), lane));
+      float T = k ? Tpart : Tin[q];
+      const bool live = hasq && pq.inside && !(T < 0.0001f);
+      if (ballot(live) != 0) {
+        const uint32_t n_my = nmy[q];
+        float Cc[3] = {0.f, 0.f, 0.f};
+        float Cv[NVF > 0 ? NVF : 1];
 #pragma unroll
-      for (int t = 0; t < (NT > 0 ? NT : 1); t++)
+        for (int i = 0; i < (NVF > 0 ? NVF : 1); i++) Cv[i] = 0.f;
+        f32x16 acc[NT > 0 ? NT : 1];
 #pragma unroll
-        for (int i = 0; i < 16; i++) { acc[t][0][i] = 0.f; acc[t][1][i] = 0.f; }
-      float alive = live ? 1.0f : 0.0f;  // 0 once the pixel has terminated (kept in a VGPR: no scalar mask algebra per entry)
-      uint32_t last = 0;
-      float Tm = T;  // transmittance entering the chunk's second group of 32 (CHS == 64)
-      // one entry of the reference's per-pixel walk (forward.cu:357-380) given its alpha: returns the blend weight
-      // alpha * T (0: not blended) and advances T / alive / last.  A live pixel always has T >= 1e-4 (it entered so, and
-      // a blend only happens when the new T stays above), hence alpha == 0 (a skipped entry) can never trip the stop
-      // test and needs no test of its own; T * (1 - a) is the reference's test_T bit for bit when a == alpha.
-      auto advance = [&](int j, float alpha) -> float {
-        const float test_T = T * (1.0f - alpha);
-        const bool term = test_T < 0.0001f;
-        const float a = (term ? 0.f : alpha) * alive;  // the entry's alpha if it is blended for this pixel, else 0
-        alive = term ? 0.f : alive;
-        const float wgt = a * T;
-        T = T * (1.0f - a);
-        last = wgt > 0.f ? (uint32_t)j + 1u : last;
-        return wgt;
-      };
-      bool stop = false;  // wave-uniform: the chunk is exhausted or every pixel has terminated
+        for (int t = 0; t < (NT > 0 ? NT : 1); t++)
 #pragma unroll
-      for (int kq = 0; kq < NKK / 2; kq++) {  // four entries = two MFMA pairs per step
-        const int j = 4 * kq;
-        if (CHS > 32 && j == 32) Tm = T;
-        stop = stop || (uint32_t)j >= n_my || ballot(alive != 0.f) == 0;
-        __builtin_amdgcn_sched_barrier(0);  // one quad at a time: hoisting later quads' alpha maths only adds live registers
-        if (!stop) {
-          float a[4], wq[4];
+          for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+        // B operand of step s: lane (k, ch = pl) holds feat[entry 2s + k][32 t + ch]: one coalesced 128-B row per entry and
+        // tile, a ring of BD steps in flight
+        constexpr int BD = 4;
+        float Bq[NT > 0 ? NT : 1][BD];
+        // The ring holds the RAW loaded values (the select that discards rows past the chunk's end sits at the use, so that
+        // the wait for a load happens BD steps after its issue, not at it); the row's Gaussian comes from LDS one step
+        // before its load is issued.
+        uint32_t gnext = __float_as_uint(rowq[w][q][k].w);  // Gaussian of entry 2s + k for the next load_B(s)
+        auto load_B = [&](int s) {
+          const uint32_t gide = gnext;                        // (0 for an entry past the chunk's end: a valid row)
+          if (s + 1 < NSTEP) gnext = __float_as_uint(rowq[w][q][2 * (s + 1) + k].w);
 #pragma unroll
-          for (int u = 0; u < 4; u++) a[u] = ((uint32_t)(j + u) < n_my) ? alpha_of(j + u) : 0.f;  // independent
+          for (int t = 0; t < (NT > 0 ? NT : 1); t++) {
+            const int ch = 32 * t + pl;
+            if constexpr (MF) Bq[t][s % BD] = r.feats[(size_t)gide * F + (ch < F ? ch : 0)];
+          }
+        };
+        if constexpr (MF) {
 #pragma unroll
-          for (int u = 0; u < 4; u++) wq[u] = advance(j + u, a[u]);                                  // the serial chain
-          if (ballot(wq[0] != 0.f || wq[1] != 0.f || wq[2] != 0.f || wq[3] != 0.f) != 0) {
+          for (int s = 0; s < BD; s++) load_B(s);
+        }
+        float alive = live ? 1.0f : 0.0f;  // 0 once the pixel has terminated (kept in a VGPR: no scalar mask algebra per entry)
+        uint32_t last = 0;
+        float Tm = T;  // transmittance entering the chunk's second group of 32
+        bool stop = false;  // wave-uniform: the chunk is exhausted or every pixel has terminated
+        constexpr int GS = 4;  // steps per straight-line group (8 entries): one stop test and one branch per group
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
-              const int ci = MF ? i : (i < F ? 3 + i : i - F);  // rowv = [features (F < 16)], r, g, b -> C = r, g, b, features
+        for (int g = 0; g < NSTEP / GS; g++) {
+          if (g * GS == NSTEP / 2) Tm = T;
+          stop = stop || (uint32_t)(2 * g * GS) >= n_my || ballot(alive != 0.f) == 0;
+          __builtin_amdgcn_sched_barrier(0);
+          if (!stop) {
 #pragma unroll
-              for (int u = 0; u < 4; u++) C[ci] += bcast_lane(rowv[i], j + u) * wq[u];
-            }
-            if constexpr (MF) {
+            for (int u4 = 0; u4 < GS; u4++) {
+              const int s = g * GS + u4;
+              float a0 = (q == 0) ? al[s] : alpha_of(s), a1 = a0;
+              swap32(a0, a1);  // a0 = alpha of entry 2s, a1 = alpha of entry 2s + 1 for my pixel, in both of its lanes
+              // two entries of the reference's per-pixel walk (forward.cu:357-380).  A live pixel always has T >= 1e-4 (it
+              // entered so, and a blend only happens when the new T stays above), hence alpha == 0 (a skipped entry) can
+              // never trip the stop test and needs no test of its own; T * (1 - a) is the reference's test_T bit for bit.
+              float wq[2];
+              const float aa[2] = {a0, a1};
 #pragma unroll
-              for (int h2 = 0; h2 < 2; h2++) {
-                const int kk = 2 * kq + h2;
-                float w0 = wq[2 * h2], w1 = wq[2 * h2 + 1];
-                swap32(w0, w1);  // w0: pixels 0..31 x (entry 2kk | 2kk+1), w1: pixels 32..63 x (entry 2kk | 2kk+1)
+              for (int u = 0; u < 2; u++) {
+                const float test_T = T * (1.0f - aa[u]);
+                const bool term = test_T < 0.0001f;
+                const float a = (term ? 0.f : aa[u]) * alive;  // the entry's alpha if it is blended for this pixel, else 0
+                alive = term ? 0.f : alive;
+                wq[u] = a * T;
+                T = T * (1.0f - a);
+                last = wq[u] > 0.f ? (uint32_t)(2 * s + u) + 1u : last;
+              }
+              const float wk = k ? wq[1] : wq[0];  // the weight of MY entry
+              const float4 rq = rowq[w][q][2 * s + k];
+              Cc[0] += rq.x * wk; Cc[1] += rq.y * wk; Cc[2] += rq.z * wk;
+              if constexpr (NVF > 0) {
+#pragma unroll
+                for (int i = 0; i < NVF; i++) Cv[i] += rowf[(((size_t)w * NS + q) * CHS + 2 * s + k) * NVF + i] * wk;
+              }
+              if constexpr (MF) {
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                  acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, Bq[t][kk % BD], acc[t][0], 0, 0, 0);
-                  acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, Bq[t][kk % BD], acc[t][1], 0, 0, 0);
+                  const bool okb = (uint32_t)(2 * s + k) < n_my && (32 * t + pl) < F && use_feat;
+                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk, okb ? Bq[t][s % BD] : 0.f, acc[t], 0, 0, 0);
                 }
+                if (s + BD < NSTEP) load_B(s + BD);  // refill the ring slot just used
               }
             }
           }
-          if constexpr (MF) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {  // refill the two ring slots just used
-              const int kk = 2 * kq + h2;
-              if (kk + BD < NKK && (uint32_t)(2 * (kk + BD)) < n_my) load_B(Bq, kk + BD);
-            }
-          }
         }
-      }
-      if (last <= 32u) Tm = T;  // nothing of the second group was blended for this pixel (Tm is then never used)
-      if constexpr (MF) {
-        // accumulators (col = channel lane & 31, row = pixel (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile) -> C[pixel lane]
-        float* tb = trs + (size_t)w * NT * 32 * TRS;
+        if (last <= 32u) Tm = T;  // nothing of the second group was blended for this pixel (Tm is then never used)
+        // the two parities' colour sums -> both lanes of the pixel
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+        for (int i = 0; i < 3; i++) Cc[i] += __uint_as_float(lane_xor<32>(__float_as_uint(Cc[i]), lane));
 #pragma unroll
-          for (int h2 = 0; h2 < 2; h2++)
+        for (int i = 0; i < NVF; i++) Cv[i] += __uint_as_float(lane_xor<32>(__float_as_uint(Cv[i]), lane));
+        MGS_TRACE(6 + 8 * round);
+        const size_t slot = (size_t)rb + (size_t)ci;
+        float* pp = partial + slot * NCH * 64 + pixq;
+        if (k == 0) {
+          T_end[slot * 64 + pixq] = T;
+          T_mid[slot * 64 + pixq] = Tm;
+          last_pos[slot * 64 + pixq] = last;
+#pragma unroll
+          for (int i = 0; i < 3; i++) pp[i * 64] = Cc[i];
+#pragma unroll
+          for (int i = 0; i < NVF; i++) pp[(3 + i) * 64] = Cv[i];
+        }
+        if constexpr (MF) {
+          // accumulators (col = channel pl, row = pixel (i & 3) + 8 (i >> 2) + 4 k of the half block) -> [channel][pixel];
+          // lane (pixel pl, k) then stores the channels k F/2 .. k F/2 + F/2 - 1 of its pixel (32 consecutive floats per row)
+          float* tb = trs + (size_t)w * NT * 32 * TRS;
+#pragma unroll
+          for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++)
-              tb[(32 * t + (lane & 31)) * TRS + 32 * h2 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)] = acc[t][h2][i];
-        wave_lds_sync();
+              tb[(32 * t + pl) * TRS + (i & 3) + 8 * (i >> 2) + 4 * k] = acc[t][i];
+          wave_lds_sync();
 #pragma unroll
-        for (int ch = 0; ch < F; ch++) C[3 + ch] = tb[ch * TRS + lane];
-        wave_lds_sync();  // the next round's writes come after these reads
+          for (int c = 0; c < F / 2; c++) {
+            const int ch = k * (F / 2) + c;
+            pp[(3 + ch) * 64] = tb[ch * TRS + pl];
+          }
+          wave_lds_sync();  // the next chunk's writes come after these reads
+        }
+        if (live) { my_vis = cbase + ci + 1; my_Tf = T; }
       }
-      MGS_TRACE(6 + 8 * round);
-      const size_t slot = (size_t)rb + (size_t)w;
-      T_end[slot * 64 + lane] = T;
-      if (CHS > 32) T_mid[slot * 64 + lane] = Tm;
-      last_pos[slot * 64 + lane] = last;
-      float* pp = partial + slot * NCH * 64 + lane;
-#pragma unroll
-      for (int i = 0; i < NCH; i++) pp[i * 64] = C[i];
-      if (live) { my_vis = c + 1; my_Tf = T; }
     }
     MGS_TRACE(7 + 8 * round);
     Tround = Tnext;
     qhead += min(avail, nchunk * CHS);
     cbase += nchunk;
-    if (ballot(p.inside && !(Tround < 0.0001f)) == 0) break;
+    if (ballot(insidex && !(Tround < 0.0001f)) == 0) break;  // all 64 pixels (each wave tracks them all): uniform
   }
 
   MGS_TRACE(TRACE_EVENTS - 3);
@@ -354,16 +411,16 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   }
   if (w == 0) { red_vis[lane] = 0; red_Tf[lane] = 1.0f; }
   __syncthreads();  // also: every wave's partial sums are written (workgroup scope)
-  if (my_vis > 0) atomicMax(&red_vis[lane], my_vis);
+  if (my_vis > 0 && k == 0) atomicMax(&red_vis[pixq], my_vis);
   __syncthreads();
-  const uint32_t vis = red_vis[lane];
-  if (my_vis > 0 && my_vis == vis) red_Tf[lane] = my_Tf;  // exactly one wave owns the last visited chunk
+  if (my_vis > 0 && k == 0 && my_vis == red_vis[pixq]) red_Tf[pixq] = my_Tf;  // exactly one wave owns a pixel's last visited chunk
   __syncthreads();
+  const uint32_t vis = red_vis[lane];   // from here on: lane = pixel of the whole block
   const float Tf = red_Tf[lane];
   // ---- image = sum of the visited chunks' partial colours, in chunk order; wave w owns channels w, w + NW, ... ----
   float img[NOWN];
 #pragma unroll
-  for (int k = 0; k < NOWN; k++) img[k] = 0.f;
+  for (int kk = 0; kk < NOWN; kk++) img[kk] = 0.f;
   const uint32_t vmax = wave_umax(vis);
   constexpr int NFLY = 8;  // records whose loads are in flight together (a block visits ~7 chunks at BASELINE configs[2])
   for (uint32_t c0 = 0; c0 < vmax; c0 += NFLY) {  // the sum stays in chunk order
@@ -375,24 +432,24 @@ coop_fwd_dense_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       const size_t slot = cc < vis ? (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (cc % NW) : 0;
       const float* pp = partial + slot * NCH * 64 + lane;
 #pragma unroll
-      for (int k = 0; k < NOWN; k++) {
-        const int ch = w + k * NW;
-        v[u][k] = (cc < vis && ch < NCH && (ch < 3 || use_feat)) ? pp[ch * 64] : 0.f;
+      for (int kk = 0; kk < NOWN; kk++) {
+        const int ch = w + kk * NW;
+        v[u][kk] = (cc < vis && ch < NCH && (ch < 3 || use_feat)) ? pp[ch * 64] : 0.f;
       }
     }
 #pragma unroll
     for (int u = 0; u < NFLY; u++)
 #pragma unroll
-      for (int k = 0; k < NOWN; k++) img[k] += v[u][k];
+      for (int kk = 0; kk < NOWN; kk++) img[kk] += v[u][kk];
   }
   MGS_TRACE(TRACE_EVENTS - 2);
   const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
   if (p.inside) {
 #pragma unroll
-    for (int k = 0; k < NOWN; k++) {
-      const int ch = w + k * NW;
-      if (ch < 3) out_color[((size_t)p.v * 3 + ch) * HW + p.pixl] = img[k] + Tf * r.bg[ch];
-      else if (ch < NCH && use_feat) out_feat[((size_t)p.v * F + (ch - 3)) * HW + p.pixl] = img[k];
+    for (int kk = 0; kk < NOWN; kk++) {
+      const int ch = w + kk * NW;
+      if (ch < 3) out_color[((size_t)p.v * 3 + ch) * HW + p.pixl] = img[kk] + Tf * r.bg[ch];
+      else if (ch < NCH && use_feat) out_feat[((size_t)p.v * F + (ch - 3)) * HW + p.pixl] = img[kk];
     }
   }
   if (w == 0) {
@@ -419,7 +476,7 @@ static hipError_t dense_F(const RenderArgs& r, const BinView& b, const ImgView& 
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
 #define MGS_CFD_(FAST, EXACT, NW, TWO)                                                                                \
-  hipLaunchKernelGGL((coop_fwd_dense_kernel<F, FAST, EXACT, NW, CHUNK, TWO>), dim3(grid), dim3(NW * 64), 0, s, r,      \
+  hipLaunchKernelGGL((coop_fwd_pairs_kernel<F, FAST, EXACT, NW, CHUNK, TWO>), dim3(grid), dim3(NW * 64), 0, s, r,      \
                      im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
                      cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of, cv.round_base, cv.pool, im.flags,   \
                      4 * T, st.host, st.tag)
