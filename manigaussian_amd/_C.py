@@ -40,6 +40,12 @@ def _f32c(t, name, dev):
     return t.contiguous()
 
 
+def _aligned16(t):
+    """The render backward reads feature rows with 16-byte loads: a contiguous view that starts at an odd offset of its
+    storage (a rare slice) is copied once."""
+    return t if (t.numel() == 0 or t.data_ptr() % 16 == 0) else t.clone()
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
 
@@ -230,6 +236,7 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         F = _padded_F(F_user)
         if F != F_user:  # feature widths that are not compiled in: zero channels change nothing
             language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+        language_feature = _aligned16(language_feature)
 
     with _on_device(dev):
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -394,6 +401,7 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
                 language_feature = _f32c(language_feature, "language_feature_precomp", dev)
                 if F != F_user:
                     language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+                language_feature = _aligned16(language_feature)
             keep = (means3D, colors, scales, rotations, cov3D_precomp, sh, language_feature)
             a = _lib.MgsRasterArgs()
             _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),

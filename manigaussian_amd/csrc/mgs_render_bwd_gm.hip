@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       const uint32_t cid = r.colors_per_view ? id : gidn;
 
       float a_mx = 0.f, a_my = 0.f, a_cx = 0.f, a_cy = 0.f, a_cz = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+      float touched = 0.f;  // > 0 iff my Gaussian was blended for one of my pixels (else all its sums are exact zeros)
       f32x16 Cf[NCT > 0 ? NCT : 1];
 #pragma unroll
       for (int ct = 0; ct < (NCT > 0 ? NCT : 1); ct++)
@@ -283,23 +284,37 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
         if (lmu == 0u) continue;
         // D = dL . row for my 16 pixels of this tile, on the matrix cores.  B operand: lane (n, h) feeds channel
         // 2t + h of its Gaussian's row (features, then r, g, b, zero padding), straight from memory.
+        // The contraction index pairs the feature channels (t, FH + t), FH = F / 2, so that lane (n, h) needs the
+        // CONTIGUOUS channels h FH .. h FH + FH - 1 of its Gaussian's row: float4 loads instead of one gather per
+        // channel (18 gathers of 4 bytes from 32 different rows each, per tile and group, at F = 32); then (r, g), (b, 0).
         f32x16 Dt;
         {
-          float bop[KCH / 2];
+          constexpr int FH = (F + 1) / 2;
+          float bop[FH + 2];
+          const float* frow = r.feats + (size_t)gidn * F + h * FH;
+          if constexpr (F > 0 && FH % 4 == 0 && F % 4 == 0) {
 #pragma unroll
-          for (int t = 0; t < KCH / 2; t++) {
-            const int c = 2 * t + h;
-            const float* src = (c < F && use_feat) ? r.feats + (size_t)gidn * F + c : r.colors + (size_t)cid * 3 + (c - F);
-            const bool okc = has && ((c < F) ? use_feat : (c < F + 3));
-            bop[t] = okc ? *src : 0.f;
+            for (int t4 = 0; t4 < FH / 4; t4++) {
+              const float4 v = (has && use_feat) ? *reinterpret_cast<const float4*>(frow + 4 * t4) : make_float4(0, 0, 0, 0);
+              bop[4 * t4] = v.x; bop[4 * t4 + 1] = v.y; bop[4 * t4 + 2] = v.z; bop[4 * t4 + 3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < FH; t++) bop[t] = (has && use_feat && h * FH + t < F) ? frow[t] : 0.f;
           }
+          const float* crow = r.colors + (size_t)cid * 3;
+          bop[FH] = has ? crow[h] : 0.f;                       // (r, g)
+          bop[FH + 1] = (has && h == 0) ? crow[2] : 0.f;       // (b, 0)
 #pragma unroll
           for (int i = 0; i < 16; i++) Dt[i] = 0.f;
 #pragma unroll
-          for (int t = 0; t < KCH / 2; t++) {
-            const float a = dLT[2 * t + h][32 * u + n];        // A[i = pixel n of tile u][k = h]
+          for (int t = 0; t < FH; t++) {
+            const int ch = h * FH + t;
+            const float a = (ch < F) ? dLT[ch < F ? ch : 0][32 * u + n] : 0.f;  // A[i = pixel n of tile u][k = h]
             Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bop[t], Dt, 0, 0, 0);  // B[k = h][j = Gaussian n]
           }
+          Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(dLT[F + h][32 * u + n], bop[FH], Dt, 0, 0, 0);
+          Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? dLT[F + 2][32 * u + n] : 0.f, bop[FH + 1], Dt, 0, 0, 0);
         }
         const float pyu = by0 + (float)(4 * u);
 #pragma unroll 1
@@ -332,6 +347,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
           a_cy += gdx * dy * dL_dG;
           a_cz += gdy * dy * dL_dG;
           a_op += G * dL_dalpha;
+          touched = act ? 1.0f : touched;
           a_r += wa * dLT[F][pp];
           a_g += wa * dLT[F + 1][pp];
           a_b += wa * dLT[F + 2][pp];
@@ -351,13 +367,16 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       if (c == (uint32_t)w) MGS_BTRACE(g == 0 ? 8 : 6);
       // ---- hand the group's sums to memory: transpose through LDS so that every atomic instruction covers whole
       //      rows (32 consecutive feature channels of one Gaussian = one 128-B line; 8 Gaussians x 6 geometry sums;
-      //      16 Gaussians x 3 colour sums) instead of 64 different lines ----
-      {
+      //      16 Gaussians x 3 colour sums) instead of 64 different lines.  (Nothing to hand over if no pixel of the
+      //      block blended anything of this group.) ----
+      if ((g == 0 ? lm0 : lm1) != 0ull) {
         float v[9] = {a_mx * ddelx_dx, a_my * ddely_dy, -0.5f * a_cx, -0.5f * a_cy, -0.5f * a_cz, a_op, a_r, a_g, a_b};
 #pragma unroll
         for (int i = 0; i < 9; i++) v[i] += __uint_as_float(lane_xor<32>(__float_as_uint(v[i]), lane));
         float* tr = trbuf[w];
-        if (h == 0) gid[w][n] = has ? make_uint2(id, gidn) : make_uint2(0xffffffffu, 0u);
+        // a Gaussian no pixel of the block blended in this group adds exact zeros everywhere: its atomics are skipped
+        const bool any_px = (touched + __uint_as_float(lane_xor<32>(__float_as_uint(touched), lane))) > 0.f;
+        if (h == 0) gid[w][n] = (has && any_px) ? make_uint2(id, gidn) : make_uint2(0xffffffffu, 0u);
         if constexpr (NCT > 0) {
           if (use_feat) {
 #pragma unroll

@@ -56,6 +56,7 @@ class _RasterizeViews(torch.autograd.Function):
             F = _C._padded_F(F_user)
             if F != F_user:
                 language_feature = torch.nn.functional.pad(language_feature, (0, F - F_user))
+            language_feature = _C._aligned16(language_feature)
         views = (_lib.MgsView * V)()
         keep = []
         for v, s in enumerate(settings):
