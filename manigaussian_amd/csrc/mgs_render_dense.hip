@@ -84,14 +84,16 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: tell the compiler (scalar branches)
   const int pr = w >> 1, hh = w & 1;         // my pair; my half block (pixel rows 4 hh .. 4 hh + 3)
-  const int k = lane >> 5, pl = lane & 31;   // my entry parity; my pixel inside the half block
+  const int k_ = lane >> 5, pl_ = lane & 31; // my entry parity; my pixel inside the half block
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;  // padding blocks of the grid (not counted in nblocks)
   const PixBlk p = pix_blk(r, tile, sub, lane);            // lane = pixel: the fill's cull and the final image sum
-  const int pixq = 32 * hh + pl;                           // my pixel in the blend phases
+  const int pixq_ = 32 * hh + pl_;                         // my pixel in the blend phases
+  const int pixq = pixq_, k = k_, pl = pl_;
   const PixBlk pq = pix_blk(r, tile, sub, pixq);
-  const int pixx = 32 * (hh ^ k) + pl;                     // the pixel whose round-to-round transmittance this lane tracks:
+  const int pixx_ = 32 * (hh ^ k) + pl;                    // the pixel whose round-to-round transmittance this lane tracks:
+  const int pixx = pixx_;
   const bool insidex = pix_blk(r, tile, sub, pixx).inside; // k = 0 lanes their own, k = 1 lanes the other half's (64 in all)
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
@@ -114,6 +116,10 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 
   const bool allocator = tid == (NW - 1) * 64;  // lane 0 of the last wave takes the rounds' chunk records from the pool
   for (;; round++) {
+    // (lane-derived indices pass through an opaque asm once per round: otherwise the compiler hoists the address arithmetic
+    //  of every unrolled LDS / global access below out of the round loop and spills it: 152 bytes of scratch per lane)
+    int k = k_, pl = pl_, pixq = pixq_, pixx = pixx_;
+    asm volatile("" : "+v"(k), "+v"(pl), "+v"(pixq), "+v"(pixx));
     // This round's chunk records: NW consecutive ones (a round blends at most NW chunks; the pool is sized from what
     // forwards actually took, so rounding up costs memory, not correctness), requested BEFORE the fill so that the
     // returning atomic's round trip hides behind it.
