@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -19,6 +20,21 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// Nonces of the preprocess's table hand-shake: a process-wide counter under a per-process random word, never 0.  Not
+// option state and not device state: two calls never share a value, that is all.
+unsigned long long next_nonce() {
+  static std::atomic<unsigned long long> counter{0};
+  static const unsigned long long salt = [] {
+    unsigned long long v = 0x9e3779b97f4a7c15ull ^ (unsigned long long)(uintptr_t)&counter;
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (f) { unsigned long long r = 0; if (fread(&r, sizeof(r), 1, f) == 1) v ^= r; fclose(f); }
+    return v << 32;
+  }();
+  const unsigned long long c = counter.fetch_add(1) + 1;
+  const unsigned long long n = salt ^ c ^ (c << 40);
+  return n ? n : 1ull;
 }
 
 static int g_profile = 0;  // diagnostics only (mgs_set_option("profile", .)): never results or layouts
@@ -235,7 +251,8 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
   segsort = segsort_binning(o, p.tiles_x * p.tiles_y);
-  MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
+  if (!segsort) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");  // (else: the preprocess does it)
+  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -695,7 +712,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
   p.tile_hist = im.tile_hist; p.blk_base = g.blk_base;
-  MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
+  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;

@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
                                                                 uint64_t* __restrict__ keys_unsorted,
                                                                 uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ seg_base,
-                                                                uint4* __restrict__ seg_desc) {
+                                                                uint4* __restrict__ seg_desc,
+                                                                unsigned long long* ready) {
   extern __shared__ uint32_t lds_u[];
   const int S = T;
   uint32_t* s_start = lds_u;          // [S] exclusive scan of the histogram
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   const int tid = threadIdx.x;
   const bool tables = (int)blockIdx.x == nblk;
   const uint32_t R = flags[FLAG_NUM_RENDERED];
+  if (tables && tid == 0 && ready) *ready = 0ull;  // the preprocess's hand-shake word: "not ready" for the next launch on this buffer
   if (tables && tid == 0 && host_status)  // report {tag, flags, R} to the host (mapped pinned memory)
     __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)(flags[FLAG_PREFILTERED] & 0xffffu) << 32) | R,
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -444,7 +446,7 @@ hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView
   // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
                      tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, g.rect, g.depths,
-                     im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc);
+                     im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready);
   switch (seg) {
     case 512: launch_sort_merge<512>(b, im, R, T, s); break;
     case 1024: launch_sort_merge<1024>(b, im, R, T, s); break;

@@ -69,6 +69,10 @@ struct ImgView {
   uint32_t* tile_hist;    // [T]    instances per tile (filled by the forward preprocess)
   uint32_t* seg_base;     // [T+1]  exclusive scan of the tiles' segment counts
   size_t zero_bytes;      // bytes from flags to the end of seg_base
+  // Hand-shake word of the forward preprocess (segment-sort binning): workgroup 0 zeroes the block above and then stores
+  // the launch's nonce here; every workgroup waits for the nonce before its first atomic on the block; the bin scatter
+  // kernel (next in the chain) stores 0 again.  Replaces a separate zero-fill launch per forward.
+  unsigned long long* ready;
 };
 
 struct BinView {
@@ -144,6 +148,7 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.tile_hist = v.flags ? v.flags + 4 : nullptr;
   v.seg_base = v.flags ? v.tile_hist + S : nullptr;
   v.zero_bytes = nz * sizeof(uint32_t);
+  v.ready = c.take<unsigned long long>(2);
   if (total) *total = c.total();
   return v;
 }
@@ -237,6 +242,10 @@ struct FwdPreArgs {
   uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
   size_t zero_f4;       // ... in float4 units
+  uint32_t* tables;     // with tile_hist: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
+  uint32_t tables_words;
+  unsigned long long* ready;  // ImgView::ready
+  unsigned long long nonce;   // this launch's (non-zero) nonce
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int prefiltered, tight_bins;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
@@ -250,6 +259,7 @@ hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
 // by the last workgroup of the render forward.  tag: 16 bits chosen by the caller (a stale write is recognisable).
 struct StatusSink { uint64_t* host; uint32_t tag; };
 // bin_mode 1: scatter -> segment sort -> rank merge
+unsigned long long next_nonce();  // process-wide counter (never 0) mixed with a per-process random word
 hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
                               int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,

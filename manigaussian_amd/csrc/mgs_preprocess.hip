@@ -116,18 +116,34 @@ template <bool HIST>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ uint32_t s_hist[];  // [tiles] when HIST: instances per tile
-  __shared__ uint32_t s_total;
-  if (HIST && threadIdx.x == 0) s_total = 0;
+  __shared__ uint32_t s_total, s_pref;
+  if (HIST && threadIdx.x == 0) { s_total = 0; s_pref = 0; }
+  // HIST launches ONE EXTRA workgroup, index 0, that only zeroes the forward's small tables (flags | tile histogram | segment
+  // bases) and publishes the launch's nonce; the working workgroups 1 .. n wait for the nonce right before their first atomic
+  // on the tables, at the very end of the kernel -- ten microseconds later.  (Workgroups are dispatched in index order, so
+  // workgroup 0 runs before anyone can wait for it.)  This replaces a zero-fill launch per forward; the bin scatter kernel
+  // resets the word, so a replayed HIP graph -- same nonce, same buffer -- starts from "not ready" again.
+  if constexpr (HIST) {
+    if (blockIdx.x == 0) {
+      for (uint32_t i = threadIdx.x; i < a.tables_words; i += blockDim.x) a.tables[i] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.nonce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  const int blk = HIST ? (int)blockIdx.x - 1 : (int)blockIdx.x;  // working workgroup
+  const int nwork = HIST ? (int)gridDim.x - 1 : (int)gridDim.x;
   // Workgroups never straddle views: view = blockIdx / (workgroups per view), so the camera is wave-uniform.
   // Single view (V == 1): gi == idx and everything below is the plain per-Gaussian preprocess.
   const int bpv = (a.Pg + (int)blockDim.x - 1) / (int)blockDim.x;
-  const int v = (int)blockIdx.x / bpv;
-  const int gi = ((int)blockIdx.x - v * bpv) * (int)blockDim.x + (int)threadIdx.x;  // Gaussian
+  const int v = blk / bpv;
+  const int gi = (blk - v * bpv) * (int)blockDim.x + (int)threadIdx.x;  // Gaussian
   const int idx = v * a.Pg + gi;                                                    // (virtual) instance owner
   const int Tv = a.tiles_x * a.tiles_y, T = Tv * a.V;
   if (a.zero_ptr) {  // fire-and-forget stores: they drain while the projection math runs
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)nwork * blockDim.x)
       a.zero_ptr[i] = z;
   }
   const bool batch = a.use_cam != 0;
@@ -141,6 +157,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   int32_t radius_out = 0;
   uint32_t touched = 0;
   int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
+  // thread 0 looks at the hand-shake word NOW (no wait: the value is examined at the end of the kernel, microseconds later,
+  // when workgroup 0's store has long arrived -- a second look is only needed if this one came too early)
+  unsigned long long seen = 0ull;
+  if (HIST && threadIdx.x == 0) seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (gi < a.Pg) {
   const float* __restrict__ vm = batch ? a.cam[v].viewmatrix : a.viewmatrix;
   const float* __restrict__ pm = batch ? a.cam[v].projmatrix : a.projmatrix;
@@ -148,7 +168,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const V3 p = ld3(a.means3D, gi);
   const float view_z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
   if (view_z <= 0.2f) {  // auxiliary.h:154 near cull
-    if (a.prefiltered) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
+    if (a.prefiltered) {
+      if constexpr (HIST) atomicOr(&s_pref, 1u);  // (handed to the flags word at the end, after the tables are ready)
+      else atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
+    }
   } else {
     const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
     const float p_w = 1.0f / (hw + 0.0000001f);
@@ -255,11 +278,19 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     for (int y = ry0; y < ry1; y++)
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     if (touched) atomicAdd(&s_total, touched);
+    if (threadIdx.x == 0) {  // the tables are zero once workgroup 0 has published this launch's nonce
+      while (seen != a.nonce) {
+        __builtin_amdgcn_s_sleep(2);
+        seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[FLAG_NUM_RENDERED], s_total);
+    if (threadIdx.x == 0 && s_pref) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
     // reserve this workgroup's slots inside every slice it contributes to; the bin scatter (same
     // PRE_BLOCK partition of the Gaussians) reads the offsets back
-    uint32_t* __restrict__ row = a.blk_base + (size_t)blockIdx.x * S;
+    uint32_t* __restrict__ row = a.blk_base + (size_t)blk * S;
     for (int t = threadIdx.x; t < S; t += blockDim.x) {
       const uint32_t c = s_hist[t];
       if (c) row[t] = atomicAdd(&a.tile_hist[t], c);
@@ -295,7 +326,7 @@ hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {  // p 4-byt
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
   if (a.tile_hist)
-    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK)), dim3(PRE_BLOCK),
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK) + 1), dim3(PRE_BLOCK),
                        sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, a, g, radii);
   else
     hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.Pg + 255) / 256), dim3(256), 0, s, a, g, radii);

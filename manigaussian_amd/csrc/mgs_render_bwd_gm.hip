@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   __syncthreads();  // qs has been read: trbuf belongs to the epilogues again
 
   const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
-  const int n = lane & 31, h = lane >> 5;
+  const int n_ = lane & 31, h_ = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
 
   for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
@@ -254,6 +254,10 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
     // ---- Gaussian-lane: groups of <= 32 entries, last group first (suffix sums run back to front) ----
     if (c == (uint32_t)w) MGS_BTRACE(5);
     for (int g = ngroups - 1; g >= 0; --g) {
+      // (lane-derived indices pass through an opaque asm once per group: otherwise the compiler hoists the address arithmetic
+      //  of the unrolled LDS accesses below out of the chunk / group loops and spills it)
+      int n = n_, h = h_;
+      asm volatile("" : "+v"(n), "+v"(h));
       const int gi = 32 * g + n;
       const bool has = gi < ns;
       GmRec rec;
@@ -310,7 +314,9 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
 #pragma unroll
           for (int t = 0; t < FH; t++) {
             const int ch = h * FH + t;
-            const float a = (ch < F) ? dLT[ch < F ? ch : 0][32 * u + n] : 0.f;  // A[i = pixel n of tile u][k = h]
+            float a;  // A[i = pixel n of tile u][k = h]
+            if constexpr (2 * FH == F) a = dLT[ch][32 * u + n];  // (every channel h FH + t exists: no per-lane guard)
+            else a = (ch < F) ? dLT[ch < F ? ch : 0][32 * u + n] : 0.f;
             Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bop[t], Dt, 0, 0, 0);  // B[k = h][j = Gaussian n]
           }
           Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(dLT[F + h][32 * u + n], bop[FH], Dt, 0, 0, 0);

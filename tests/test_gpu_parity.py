@@ -366,6 +366,58 @@ def _impl_test_async_overflow_is_reported_loudly_and_recovers():
         assert st.marks[key][0] >= good[0] and st.marks[key][1] is not None and st.marks[key][1] >= good[1]
 
 
+def test_async_overflow_of_a_view_batch_is_repaired_at_backward_entry():
+    """The same repair for GaussianRasterizerBatch (mgs_rasterize_forward_views): marks far too small, the report is in before
+    the backward -> re-rendered on the blocking path, a warning, images and gradients of the blocking path."""
+    import warnings
+    import manigaussian_amd as mg
+    from manigaussian_amd import GaussianRasterizerBatch, _state
+    with _marks_only():
+        dev = torch.device("cuda:0")
+        P, F, V, W = 5000, 32, 3, 64
+        sc, cams, dC, dF = _batch_case(P, F, V, W, W)
+        sets = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, bg=(0.1, 0.2, 0.3), device=dev))
+                for c in cams]
+        rast = GaussianRasterizerBatch(sets)
+        dCd, dFd = dC.to(dev), dF.to(dev)
+
+        def step(between=None):
+            d = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+            c, f, r = rast(d["means3D"], None, d["opacities"], shs=d["shs"], language_feature_precomp=d["language_feature"],
+                           scales=d["scales"], rotations=d["rotations"])
+            if between is not None:
+                between()
+            gs = torch.autograd.grad([c, f], list(d.values()), [dCd, dFd])
+            return c, f, r, gs
+
+        mg.set_forward_mode("blocking")
+        try:
+            c0, f0, r0, g0 = step()
+            torch.cuda.synchronize()
+        finally:
+            mg.set_forward_mode("async")
+        for _ in range(3):
+            step()
+            mg.check_status(dev)
+        st = _state.device_state(dev)
+        key = ("views", V, P, W, W, F, 1)
+        good = list(st.marks[key])
+        for bad in ([64, good[1]], [good[0], 1]):
+            st.marks[key] = list(bad)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                c1, f1, r1, g1 = step(between=torch.cuda.synchronize)
+                torch.cuda.synchronize()
+                mg.check_status(dev)
+            assert any("outgrew the workspace" in str(x.message) for x in w)
+            assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+            for a_, b_ in zip(g1, g0):
+                assert (a_ - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-12
+            for _ in range(3):
+                step()
+                mg.check_status(dev)
+
+
 def test_raw_C_forward_backward_pair_agrees_with_the_autograd_path():
     """The reference-shaped pybind pair _C.rasterize_gaussians -> _C.rasterize_gaussians_backward(R: int, binningBuffer)
     (RAST/rasterize_points.cu:35-225): the backward is handed nothing but the three byte buffers and the count, so forward
