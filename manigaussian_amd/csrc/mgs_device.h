@@ -134,13 +134,40 @@ __device__ __forceinline__ float wave_sum_shfl(float v) {
   return v;
 }
 
+// Maximum over the 64 lanes, in every lane.  DPP / permlane butterflies: no LDS, and -- unlike __shfl_xor's ds_bpermute -- no
+// per-lane address registers for the compiler to hoist out of the callers' loops and spill (round 3: four scratch reloads
+// per chunk of the render backward, 4 600 cycles, were exactly that).
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-    v = o > v ? o : v;
-  }
+  const int lane = lane_id();
+  uint32_t o;
+  o = lane_xor<1>(v, lane); v = o > v ? o : v;
+  o = lane_xor<2>(v, lane); v = o > v ? o : v;
+  o = lane_xor<4>(v, lane); v = o > v ? o : v;
+  o = lane_xor<8>(v, lane); v = o > v ? o : v;
+  o = lane_xor<16>(v, lane); v = o > v ? o : v;
+  o = lane_xor<32>(v, lane); v = o > v ? o : v;
   return v;
+}
+
+// Inclusive prefix sum over the 64 lanes (uint32): row_shr steps inside the rows of 16, row_bcast:15 / row_bcast:31 across them.
+// Lanes without a DPP source keep their value (bound_ctrl off).  One asm block, like the float scans above.
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v) {
+  uint32_t r = v;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+&v"(r) : "v"(v));
+  return r;
 }
 
 }  // namespace mgs

@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
     pd[w][lane] = make_float4((live0 && w > 0) ? pf_Tin : 1.0f, live0 ? pf_B + bgT : 0.f, __uint_as_float(pf_last), pf_Tmid);
     rec0[w][lane] = pf_g0; rec1[w][lane] = pf_g1; recid[w][lane] = pf_id;
   }
+  MGS_BTRACE(10);
   __syncthreads();  // qs has been read: trbuf belongs to the epilogues again
+  MGS_BTRACE(11);
 
   const float ddelx_dx = 0.5f * r.W, ddely_dy = 0.5f * r.Hv;
   const int n_ = lane & 31, h_ = lane >> 5;

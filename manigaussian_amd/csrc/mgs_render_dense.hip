@@ -153,12 +153,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       __syncthreads();
       // exclusive prefix over the FILLK * NW counters (sub-step major = list order), one counter per lane
       const uint32_t v = lane < FILLK * NW ? cnt[fill & 1][lane] : 0u;
-      uint32_t incl = v;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-        incl += lane >= d ? up : 0u;
-      }
+      const uint32_t incl = wave_incl_scan_add_u32(v);
       const uint32_t total = bcast_lane_u32(incl, 63);
 #pragma unroll
       for (int kf = 0; kf < FILLK; kf++) {

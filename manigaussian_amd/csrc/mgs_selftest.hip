@@ -19,6 +19,13 @@ __global__ void selftest_kernel(int* result) {
   if (bcast_lane((float)lane, 37) != 37.f) bad |= 2048;
   if (bcast_lane_u32((uint32_t)lane * 5u, 63) != 315u) bad |= 4096;
   if (wave_umax((uint32_t)lane * 3u) != 189u) bad |= 8192;
+  if (wave_umax((uint32_t)((lane * 37) % 64)) != 63u) bad |= 8192;
+  {  // 64-lane inclusive prefix sum
+    const uint32_t x = (uint32_t)((lane * 7) % 5 + 1);
+    uint32_t e = 0;
+    for (int i = 0; i <= lane; i++) e += (uint32_t)((i * 7) % 5 + 1);
+    if (wave_incl_scan_add_u32(x) != e) bad |= 1 << 24;
+  }
   {
     const uint32_t v = (uint32_t)lane * 2654435761u;
     if (lane_xor<1>(v, lane) != (uint32_t)(lane ^ 1) * 2654435761u) bad |= 1 << 14;

@@ -36,7 +36,7 @@ assert _lib.lib().mgs_debug_read_trace_bwd(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(512, 16, EV).astype(np.int64)[:256]
 t0 = np.where(t[:, :, 0] > 0, t[:, :, 0], np.iinfo(np.int64).max).min(1)
 rel = np.where(t > 0, t - t0[:, None, None], -1)
-names = {0: "entry", 1: "dL loaded", 2: "q written", 3: "barrier", 4: "chunk state (B, T_in)", 5: "records staged",
+names = {0: "entry", 1: "dL loaded", 2: "q written", 3: "barrier", 10: "first chunk staged", 11: "barrier 2", 4: "chunk state (B, T_in)", 5: "records staged",
          6: "group 1 pixel loops", 7: "group 1 sums out", 8: "group 0 pixel loops", 9: "group 0 sums out", 15: "exit"}
 print("shader-clock cycles since the block's first stamp; per block the LAST wave that stamped the event")
 for e, n in names.items():
