@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   constexpr int TROW = NCT * 32 + 9;      // per wave: [32 Gaussians][feature sums | 9 scalar sums], odd stride
   __shared__ float trbuf[NW][32 * TROW];
   __shared__ uint2 gid[NW][32];           // per wave: {instance id, Gaussian} of the group's lanes (0xffffffff: empty lane)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: scalar chunk loops and addresses
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;
@@ -115,27 +116,41 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   const uint32_t lcmax = wave_umax(lc);
   if (lcmax == 0) return;
   const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+  // (Measured, profiles/r03_exp_bwd_units.log: cutting a block's chunks into (chunk, pixel tile) units so that the ~9 idle
+  //  waves of a block at BASELINE configs[2] take half of a chunk each does NOT pay: without the atomics the kernel goes from
+  //  45 to 43 us only -- the pixel steps are issue-bound per SIMD, not latency-bound per wave -- and with twice the atomics
+  //  (each unit hands over its own sums) it takes 73 us: the L2's float atomics are the scarce unit, see the epilogue.)
   const uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);
   // records of round 0 start at nsv.y (one load, no table, no barrier); later rounds (rare) go through the table in LDS
   if (tid >= 1 && tid < (int)RBH && (uint32_t)tid * NWF < lcmax) rb_hist[tid] = my_rounds[4 * (size_t)tid];
   if (tid == 0) rb_hist[0] = nsv.y;
+  // (c is wave-uniform.  Three sources behind three BRANCHES: written as one select, the compiler merges the LDS and the
+  //  memory read into a flat load of a selected address with a full s_waitcnt behind it -- every loop over chunks below
+  //  then runs one serialised round trip per chunk.  The atomic load keeps the rare memory read a separate instruction.)
   auto slot_of = [&](uint32_t c) -> size_t {
     const uint32_t rr = c / NWF;
-    return (size_t)(rr == 0 ? nsv.y : (rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr])) + (size_t)(c % NWF);
+    uint32_t b = nsv.y;
+    if (rr != 0u) {
+      b = rb_hist[rr < RBH ? rr : 1u];
+      if (__builtin_expect(rr >= RBH, 0))
+        b = __hip_atomic_load(&my_rounds[4 * (size_t)rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return (size_t)b + (size_t)(c % NWF);
   };
   if (lcmax > NWF) __syncthreads();  // (workgroup-uniform) only blocks with a second round read the table
   // ---- this wave's FIRST chunk (c = w): its per-pixel state and its survivors' records are requested now, so that they
   //      arrive while q is being computed (they used to be three more round trips after the barrier) ----
   const bool pf = (uint32_t)w < lcmax;
+  const uint32_t c1 = (uint32_t)w;            // my first chunk
   uint32_t pf_last = 0u, pf_id = 0u;
   float pf_Tin = 1.0f, pf_Tmid = 1.0f;
   float4 pf_g0 = make_float4(0, 0, 0, 0), pf_g1 = make_float4(0, 0, -1.f, -1.f);
   if (pf) {
-    const size_t slot0 = slot_of((uint32_t)w);
-    if ((uint32_t)w < lc) pf_last = last_pos[slot0 * 64 + lane];
+    const size_t slot0 = slot_of(c1);
+    if (c1 < lc) pf_last = last_pos[slot0 * 64 + lane];
     pf_Tmid = T_mid[slot0 * 64 + lane];
-    if (w > 0) pf_Tin = T_end[slot_of((uint32_t)w - 1u) * 64 + lane];
-    const uint32_t first = (uint32_t)w * (uint32_t)CH;
+    if (c1 > 0) pf_Tin = T_end[slot_of(c1 - 1u) * 64 + lane];
+    const uint32_t first = c1 * (uint32_t)CH;
     const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
     if ((uint32_t)lane < nin) {
       pf_id = surv[(size_t)sub * surv_stride + rng.x + first + (uint32_t)lane];
@@ -152,7 +167,12 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
     for (int i = 0; i < (F > 0 ? F : 1); i++) dLf[i] = 0.f;
   }
   float bgT = 0.f;
-  float* qs = &trbuf[0][0];  // q of the block's first NW chunks, [chunk][pixel]: trbuf is idle until the first epilogue
+  float* qs = &trbuf[0][0];  // q of the block's first QCAP chunks, [chunk][pixel]: trbuf is idle until the first epilogue
+  constexpr uint32_t QCAP = (uint32_t)(NW * 32 * TROW / 64);
+  // (workgroup-uniform) every q of the block fits in LDS: each wave then forms the sums behind ALL its chunks here, one pass
+  // over qs, and parks those of its later chunks in q's own records (which only it reads again).  Otherwise (lists of more
+  // than QCAP * 64 survivors per block) q goes to memory and every chunk sums what lies behind it from there.
+  const bool fastB = lcmax <= QCAP;
   {
     bgT = T_final * (r.bg[0] * dLc[0] + r.bg[1] * dLc[1] + r.bg[2] * dLc[2]);
     if (w == 0) {
@@ -180,8 +200,8 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
           }
         }
       }
-      q[slot * 64 + lane] = s;
-      if (c < (uint32_t)NW) qs[c * 64 + (uint32_t)lane] = s;
+      if (!fastB) q[slot * 64 + lane] = s;
+      if (c < QCAP) qs[c * 64 + (uint32_t)lane] = s;
     }
   }
   MGS_BTRACE(2);
@@ -192,16 +212,30 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   if (pf) {
     const bool live0 = pf_last > 0u;
     float pf_B = 0.f;
-    const uint32_t cl = min(lcmax, (uint32_t)NW);
-    for (uint32_t c2 = (uint32_t)w + 1u; c2 < cl; c2++) {
-      const float v = qs[c2 * 64 + (uint32_t)lane];
-      pf_B += (live0 && c2 < lc) ? v : 0.f;
+    if (fastB) {
+      // my chunks from the last one down to the first, one running sum (back to front, chunk order)
+      uint32_t hi = lcmax;  // the sum holds q[hi .. lcmax)
+      for (uint32_t c = (uint32_t)w + ((lcmax - 1u - (uint32_t)w) / (uint32_t)NW) * (uint32_t)NW;; c -= (uint32_t)NW) {
+        for (uint32_t c2 = hi; c2-- > c + 1u;) {
+          const float v = qs[c2 * 64 + (uint32_t)lane];
+          pf_B += (c2 < lc) ? v : 0.f;
+        }
+        hi = c + 1u;
+        if (c == (uint32_t)w) break;
+        q[slot_of(c) * 64 + lane] = pf_B;
+      }
+    } else {
+      const uint32_t cl = min(lcmax, QCAP);
+      for (uint32_t c2 = c1 + 1u; c2 < cl; c2++) {
+        const float v = qs[c2 * 64 + (uint32_t)lane];
+        pf_B += (c2 < lc) ? v : 0.f;
+      }
+      for (uint32_t c2 = max(c1 + 1u, QCAP); c2 < lcmax; c2++) {
+        const float v = q[slot_of(c2) * 64 + lane];
+        pf_B += (c2 < lc) ? v : 0.f;
+      }
     }
-    for (uint32_t c2 = max((uint32_t)w + 1u, (uint32_t)NW); c2 < lcmax; c2++) {
-      const float v = q[slot_of(c2) * 64 + lane];
-      pf_B += (live0 && c2 < lc) ? v : 0.f;
-    }
-    pd[w][lane] = make_float4((live0 && w > 0) ? pf_Tin : 1.0f, live0 ? pf_B + bgT : 0.f, __uint_as_float(pf_last), pf_Tmid);
+    pd[w][lane] = make_float4((live0 && c1 > 0) ? pf_Tin : 1.0f, live0 ? pf_B + bgT : 0.f, __uint_as_float(pf_last), pf_Tmid);
     rec0[w][lane] = pf_g0; rec1[w][lane] = pf_g1; recid[w][lane] = pf_id;
   }
   MGS_BTRACE(10);
@@ -233,9 +267,13 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       if (ns == 0) continue;
       if (!first_it) {
         float B = 0.f;
-        for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
-          const float v = q[slot_of(c2) * 64 + lane];
-          B += (live && c2 < lc) ? v : 0.f;
+        if (fastB) {
+          B = q[slot * 64 + lane];  // parked by the prologue
+        } else {
+          for (uint32_t c2 = c + 1; c2 < lcmax; c2++) {
+            const float v = q[slot_of(c2) * 64 + lane];
+            B += (c2 < lc) ? v : 0.f;
+          }
         }
         const float T_in = (live && c > 0) ? T_end[slot_of(c - 1) * 64 + lane] : 1.0f;
         // ---- entry-lane: the chunk's survivors (the forward listed them in order) ----
@@ -254,7 +292,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
     const int ngroups = (ns + 31) >> 5;
 
     // ---- Gaussian-lane: groups of <= 32 entries, last group first (suffix sums run back to front) ----
-    if (c == (uint32_t)w) MGS_BTRACE(5);
+    if (first_it) MGS_BTRACE(5);
     for (int g = ngroups - 1; g >= 0; --g) {
       // (lane-derived indices pass through an opaque asm once per group: otherwise the compiler hoists the address arithmetic
       //  of the unrolled LDS accesses below out of the chunk / group loops and spills it)
@@ -372,7 +410,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       }
       if (g > 0) wave_lds_sync();  // pd[].y updates visible before the next group reads them
 
-      if (c == (uint32_t)w) MGS_BTRACE(g == 0 ? 8 : 6);
+      if (first_it) MGS_BTRACE(g == 0 ? 8 : 6);
       // ---- hand the group's sums to memory: transpose through LDS so that every atomic instruction covers whole
       //      rows (32 consecutive feature channels of one Gaussian = one 128-B line; 8 Gaussians x 6 geometry sums;
       //      16 Gaussians x 3 colour sums) instead of 64 different lines.  (Nothing to hand over if no pixel of the
@@ -423,7 +461,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
                             tr[gg * TROW + NCT * 32 + 6 + i]);
         }
         wave_lds_sync();  // tr / gid are rewritten by the next group
-        if (c == (uint32_t)w) MGS_BTRACE(g == 0 ? 9 : 7);
+        if (first_it) MGS_BTRACE(g == 0 ? 9 : 7);
       }
     }
   }

@@ -75,8 +75,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   __shared__ float4 rowq[NW][NS][CHS];       // per wave and chunk slot, for the blend: {r, g, b, Gaussian (bits)}
   __shared__ float rowf[NVF > 0 ? NW * NS * CHS * NVF : 1];  // ... and the feature row when it is blended on the VALU
   __shared__ float Tp[2][NW][64];            // per-chunk transmittance products [chunk of the round][pixel], double buffered
-  __shared__ float red_Tf[64];
-  __shared__ uint32_t red_vis[64];
+  __shared__ unsigned long long red_last[64];  // per pixel: (last visited chunk + 1) << 32 | bits of the transmittance after it
   __shared__ uint32_t cnt[2][FILLK * NW];    // survivors per (sub-step, wave) of a fill step, double buffered
   __shared__ uint32_t rbase[2];              // first chunk record of the round (pool index), double buffered over rounds
   constexpr uint32_t RBH = 16;               // rounds whose first record is also kept in LDS for the final sum
@@ -104,6 +103,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   float Tround = 1.0f;     // transmittance of pixel pixx entering the round
   uint32_t my_vis = 0;
   float my_Tf = 1.0f;
+  if (w == 0) red_last[lane] = (unsigned long long)__float_as_uint(1.0f);  // (ordered by the first round's barrier)
   MGS_TRACE(0);
 
   // all of these are workgroup-uniform (every thread derives them from the same LDS counts)
@@ -401,36 +401,33 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   }
 
   MGS_TRACE(TRACE_EVENTS - 3);
-  // This block has taken its last chunk records: count it now (the returned ticket is looked at after the final sum, so
-  // the atomic's round trip is hidden); whoever draws the last ticket reports the pool usage to the host.
-  uint32_t ticket = 0;
-  if (tid == 0) {
-    // (device-scope atomics served by the L2; the OR's returned value feeds the ticket, so it has been performed when the
-    //  ticket is counted -- no fence: a fence here costs every block ~3 us)
-    const uint32_t dep = overflow ? (atomicOr(&flags[FLAG_PREFILTERED], 0x100u) & 0u) : 0u;
-    ticket = atomicAdd(&flags[FLAG_BLOCKS_DONE], 1u + dep) + 1u;
-  }
-  if (w == 0) { red_vis[lane] = 0; red_Tf[lane] = 1.0f; }
+  // exactly one wave owns a pixel's last visited chunk: the 64-bit maximum carries its transmittance along
+  if (my_vis > 0 && k == 0)
+    atomicMax(&red_last[pixq], ((unsigned long long)my_vis << 32) | (unsigned long long)__float_as_uint(my_Tf));
   __syncthreads();  // also: every wave's partial sums are written (workgroup scope)
-  if (my_vis > 0 && k == 0) atomicMax(&red_vis[pixq], my_vis);
-  __syncthreads();
-  if (my_vis > 0 && k == 0 && my_vis == red_vis[pixq]) red_Tf[pixq] = my_Tf;  // exactly one wave owns a pixel's last visited chunk
-  __syncthreads();
-  const uint32_t vis = red_vis[lane];   // from here on: lane = pixel of the whole block
-  const float Tf = red_Tf[lane];
+  const unsigned long long rl = red_last[lane];   // from here on: lane = pixel of the whole block
+  const uint32_t vis = (uint32_t)(rl >> 32);
+  const float Tf = __uint_as_float((uint32_t)rl);
   // ---- image = sum of the visited chunks' partial colours, in chunk order; wave w owns channels w, w + NW, ... ----
   float img[NOWN];
 #pragma unroll
   for (int kk = 0; kk < NOWN; kk++) img[kk] = 0.f;
   const uint32_t vmax = wave_umax(vis);
   constexpr int NFLY = 8;  // records whose loads are in flight together (a block visits ~7 chunks at BASELINE configs[2])
+  static_assert(NW % NFLY == 0, "a batch of the final sum lies inside one round");
   for (uint32_t c0 = 0; c0 < vmax; c0 += NFLY) {  // the sum stays in chunk order
     float v[NFLY][NOWN];
+    // the round's first record, ONE wave-uniform read per batch and decided by a branch: a per-chunk select between the
+    // LDS copy and the one in memory compiles to a flat load with a full wait per chunk, which serialises the batch
+    const uint32_t rr = c0 / NW;
+    uint32_t rb0 = rb_hist[rr < RBH ? rr : 0u];                              // (unconditional LDS read ...
+    if (__builtin_expect(rr >= RBH, 0))                                      //  ... and a rarely taken branch; the atomic
+      rb0 = __hip_atomic_load(&my_rounds[4 * (size_t)rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // load is not merged)
+    rb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb0);
 #pragma unroll
     for (int u = 0; u < NFLY; u++) {
       const uint32_t cc = c0 + u;
-      const uint32_t rr = cc / NW;
-      const size_t slot = cc < vis ? (size_t)(rr < RBH ? rb_hist[rr] : my_rounds[4 * (size_t)rr]) + (cc % NW) : 0;
+      const size_t slot = cc < vis ? (size_t)rb0 + (cc % NW) : 0;
       const float* pp = partial + slot * NCH * 64 + lane;
 #pragma unroll
       for (int kk = 0; kk < NOWN; kk++) {
@@ -444,6 +441,16 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       for (int kk = 0; kk < NOWN; kk++) img[kk] += v[u][kk];
   }
   MGS_TRACE(TRACE_EVENTS - 2);
+  // This block has taken its last chunk records: count it (after the sum: the wait for the returning ticket would
+  // otherwise hold wave 0, and with it everyone, at the barrier above); whoever draws the last ticket reports the pool
+  // usage to the host.
+  uint32_t ticket = 0;
+  if (tid == 0) {
+    // (device-scope atomics served by the L2; the OR's returned value feeds the ticket, so it has been performed when the
+    //  ticket is counted -- no fence: a fence here costs every block ~3 us)
+    const uint32_t dep = overflow ? (atomicOr(&flags[FLAG_PREFILTERED], 0x100u) & 0u) : 0u;
+    ticket = atomicAdd(&flags[FLAG_BLOCKS_DONE], 1u + dep) + 1u;
+  }
   const size_t HW = (size_t)r.Hv * r.W;  // one image plane of one view
   if (p.inside) {
 #pragma unroll
