@@ -279,7 +279,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     if (touched) atomicAdd(&s_total, touched);
     if (threadIdx.x == 0) {  // the tables are zero once workgroup 0 has published this launch's nonce
-      while (seen != a.nonce) {
+      // (workgroup 0 is dispatched first and needs ~2 us; the bound turns a wait that can never end -- a device that lost the
+      //  store -- into a failed launch the host reports, after about a second, instead of a hung queue)
+      for (uint32_t polls = 0; seen != a.nonce; polls++) {
+        if (polls == (1u << 23)) __builtin_trap();
         __builtin_amdgcn_s_sleep(2);
         seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

@@ -69,7 +69,10 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   constexpr uint32_t FSTEP = NW * 64;        // entries examined per fill sub-step (one per thread)
   constexpr int FILLK = 3;                   // sub-steps per fill step (all loads in flight together): at BASELINE configs[2]
                                              // a block needs ~2400 list entries for its first 1024 survivors -- one step, not two
-  __shared__ float trs[MF ? NW * NT * 32 * TRS : 1];  // per wave: [channel][pixel] hand-over of the MFMA accumulators
+  constexpr int TRR = NT * 32 + 3;           // rows of a wave's hand-over buffer: the feature channels, then r, g, b
+  __shared__ float trs[MF ? NW * TRR * TRS : 1];      // per wave: [channel][pixel] hand-over of the MFMA accumulators; after the
+                                             // rounds it still holds the wave's LAST chunk: the final sum reads that one here
+  __shared__ uint32_t lastcc[NW];            // ... its dense chunk index (0xffffffff: the wave blended nothing)
   __shared__ float4 recA[NW][CHS];           // per wave, the chunk under evaluation: {x, y, conic.x, conic.y}
   __shared__ float2 recB[NW][CHS];           //                                       {conic.z, opacity (0: no entry)}
   __shared__ float4 rowq[NW][NS][CHS];       // per wave and chunk slot, for the blend: {r, g, b, Gaussian (bits)}
@@ -104,6 +107,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   uint32_t my_vis = 0;
   float my_Tf = 1.0f;
   if (w == 0) red_last[lane] = (unsigned long long)__float_as_uint(1.0f);  // (ordered by the first round's barrier)
+  uint32_t my_lastcc = 0xffffffffu;  // wave-uniform
   MGS_TRACE(0);
 
   // all of these are workgroup-uniform (every thread derives them from the same LDS counts)
@@ -251,6 +255,10 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     }
     MGS_TRACE(4 + 8 * round);
     __syncthreads();
+    // every load of this round so far has been consumed; saying so (s_waitcnt vmcnt(0), free here) keeps the compiler from
+    // protecting registers it believes still awaited further down -- behind this round's stores, whose drain that wait would
+    // then include (one in-order counter for loads and stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     MGS_TRACE(5 + 8 * round);
     const uint32_t rb = rbase[round & 1];
     if (rb + (uint32_t)NW > pool) { overflow = true; break; }  // uniform: every thread reads the same word
@@ -355,6 +363,15 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
             }
           }
         }
+        if constexpr (MF) {
+          // A walk that stops early leaves ring loads in flight whose registers are reused later: the compiler then waits for
+          // them THERE -- after this chunk's stores, and (one in-order counter) for those stores as well: every block drained
+          // its stores at the barrier before the final sum.  Touching the ring here puts that wait before the stores.
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < BD; i++) asm volatile("" ::"v"(Bq[t][i]));
+        }
         if (last <= 32u) Tm = T;  // nothing of the second group was blended for this pixel (Tm is then never used)
         // the two parities' colour sums -> both lanes of the pixel
 #pragma unroll
@@ -376,12 +393,16 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
         if constexpr (MF) {
           // accumulators (col = channel pl, row = pixel (i & 3) + 8 (i >> 2) + 4 k of the half block) -> [channel][pixel];
           // lane (pixel pl, k) then stores the channels k F/2 .. k F/2 + F/2 - 1 of its pixel (32 consecutive floats per row)
-          float* tb = trs + (size_t)w * NT * 32 * TRS;
+          float* tb = trs + (size_t)w * TRR * TRS;
 #pragma unroll
           for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++)
               tb[(32 * t + pl) * TRS + (i & 3) + 8 * (i >> 2) + 4 * k] = acc[t][i];
+          if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) tb[(NT * 32 + i) * TRS + pl] = Cc[i];
+          }
           wave_lds_sync();
 #pragma unroll
           for (int c = 0; c < F / 2; c++) {
@@ -389,6 +410,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
             pp[(3 + ch) * 64] = tb[ch * TRS + pl];
           }
           wave_lds_sync();  // the next chunk's writes come after these reads
+          my_lastcc = cbase + ci;
         }
         if (live) { my_vis = cbase + ci + 1; my_Tf = T; }
       }
@@ -404,6 +426,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   // exactly one wave owns a pixel's last visited chunk: the 64-bit maximum carries its transmittance along
   if (my_vis > 0 && k == 0)
     atomicMax(&red_last[pixq], ((unsigned long long)my_vis << 32) | (unsigned long long)__float_as_uint(my_Tf));
+  if constexpr (MF) { if (lane == 0) lastcc[w] = my_lastcc; }
   __syncthreads();  // also: every wave's partial sums are written (workgroup scope)
   const unsigned long long rl = red_last[lane];   // from here on: lane = pixel of the whole block
   const uint32_t vis = (uint32_t)(rl >> 32);
@@ -424,15 +447,53 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     if (__builtin_expect(rr >= RBH, 0))                                      //  ... and a rarely taken branch; the atomic
       rb0 = __hip_atomic_load(&my_rounds[4 * (size_t)rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // load is not merged)
     rb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb0);
+    // A chunk that was the LAST one of the wave that blended it (at BASELINE configs[2]: every chunk of 85 % of the blocks)
+    // is still in that wave's hand-over buffer: it is read from LDS, and only the others come from memory -- where the
+    // loads queue behind this block's own stores of a moment ago.  Same values, same order either way.
+    bool inl[NFLY];
+    unsigned long long needg = 0ull;
 #pragma unroll
     for (int u = 0; u < NFLY; u++) {
       const uint32_t cc = c0 + u;
-      const size_t slot = cc < vis ? (size_t)rb0 + (cc % NW) : 0;
-      const float* pp = partial + slot * NCH * 64 + lane;
+      inl[u] = false;
+      if constexpr (MF) {
+        const uint32_t ws = 2u * ((cc % NW) % NP) + (uint32_t)(lane >> 5);  // the wave that blended my pixel's half of chunk cc
+        inl[u] = lastcc[ws] == cc;
+      }
+      needg |= ballot(cc < vis && !inl[u]);
 #pragma unroll
-      for (int kk = 0; kk < NOWN; kk++) {
-        const int ch = w + kk * NW;
-        v[u][kk] = (cc < vis && ch < NCH && (ch < 3 || use_feat)) ? pp[ch * 64] : 0.f;
+      for (int kk = 0; kk < NOWN; kk++) v[u][kk] = 0.f;
+    }
+    if (needg != 0ull) {  // (wave-uniform: the wait for these loads, and with it for the stores ahead of them, is in here)
+#pragma unroll
+      for (int u = 0; u < NFLY; u++) {
+        const uint32_t cc = c0 + u;
+        const bool gl = cc < vis && !inl[u];
+        const size_t slot = gl ? (size_t)rb0 + (cc % NW) : 0;
+        const float* pp = partial + slot * NCH * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < NOWN; kk++) {
+          const int ch = w + kk * NW;
+          if (gl && ch < NCH && (ch < 3 || use_feat)) v[u][kk] = pp[ch * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NFLY; u++)
+#pragma unroll
+        for (int kk = 0; kk < NOWN; kk++) asm volatile("" : "+v"(v[u][kk]));  // (the wait stays inside the branch)
+    }
+    if constexpr (MF) {
+#pragma unroll
+      for (int u = 0; u < NFLY; u++) {
+        const uint32_t cc = c0 + u;
+        const uint32_t ws = 2u * ((cc % NW) % NP) + (uint32_t)(lane >> 5);
+        const float* tb = trs + (size_t)ws * TRR * TRS + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < NOWN; kk++) {
+          const int ch = w + kk * NW;
+          const int row = ch < 3 ? NT * 32 + ch : ch - 3;  // hand-over rows: features first, then r, g, b
+          if (cc < vis && inl[u] && ch < NCH && (ch < 3 || use_feat)) v[u][kk] = tb[row * TRS];
+        }
       }
     }
 #pragma unroll
