@@ -343,17 +343,37 @@ __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* _
   if (e0 + 1u < cnt) keys[base + e0 + 1u] = k1;
 }
 
-// lower_bound of key in the sorted LDS array a[0..len), len <= SEGN: fixed trip count, branch-free
+// lower bounds of two keys in the sorted LDS array a[0..len), len <= SEGN and WAVE-UNIFORM (every lane ranks in the same
+// segment).  Bounded branch-free search: the first probe, at the largest power of two P <= len, picks the window a[0..P) or
+// a[len-P..len) (everything before it is then known to be smaller); log2 P halvings and one last probe finish inside the
+// window -- no probe ever needs a bounds test.  (The previous version clamped every probe with min(q, len) and combined
+// `q <= len && v < key` per step: two scalar mask operations per step and key on the CU's one scalar unit, which is what
+// bound this kernel at long lists: 56.9 M SALU against 36.7 M VALU instructions per launch at the configs[4] shape,
+// profiles/r02_sq_counters_c5shape.json.)
 template <int SEGN>
-__device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t* a, uint32_t len, uint64_t key) {
-  uint32_t pos = 0;
-#pragma unroll
-  for (uint32_t s = SEGN; s >= 1; s >>= 1) {
-    const uint32_t q = pos + s;
-    const uint64_t v = a[min(q, len) - 1u + (len == 0u ? 1u : 0u)];
-    pos = (q <= len && v < key) ? q : pos;
+__device__ __forceinline__ void lds_lower_bound2(const uint64_t* a, uint32_t len, uint64_t k0, uint64_t k1, uint32_t& q0,
+                                                 uint32_t& q1) {
+  q0 = 0u; q1 = 0u;
+  if (len == 0u) return;
+  const uint32_t P = 1u << (31 - __builtin_clz(len));
+  {
+    const uint64_t v = a[P - 1u];
+    q0 = v < k0 ? len - P : 0u;
+    q1 = v < k1 ? len - P : 0u;
   }
-  return pos;
+#pragma unroll
+  for (uint32_t h = SEGN / 2; h >= 1u; h >>= 1) {
+    if (h < P) {  // (wave-uniform)
+      const uint64_t v0 = a[q0 + h - 1u], v1 = a[q1 + h - 1u];
+      q0 += v0 < k0 ? h : 0u;
+      q1 += v1 < k1 ? h : 0u;
+    }
+  }
+  {
+    const uint64_t v0 = a[q0], v1 = a[q1];
+    q0 += v0 < k0 ? 1u : 0u;
+    q1 += v1 < k1 ? 1u : 0u;
+  }
 }
 
 // K6': final position of a key = its index + its lower-bound rank in the tile's other segments (keys are unique),
@@ -415,8 +435,8 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     for (uint32_t s2 = s0; s2 < s1; s2++) {
       if (s2 == self) continue;
       const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
-      const uint32_t q0 = lds_lower_bound<SEGN>(sk + o2, len, key[0]);
-      const uint32_t q1 = lds_lower_bound<SEGN>(sk + o2, len, key[1]);
+      uint32_t q0, q1;
+      lds_lower_bound2<SEGN>(sk + o2, len, key[0], key[1], q0, q1);
       rank[0] += q0;
       rank[1] += q1;
     }
