@@ -242,6 +242,7 @@ struct FwdPreArgs {
   uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
   size_t zero_f4;       // ... in float4 units
+  int zero_blocks;      // workgroups at the end of the grid that do nothing else (set by launch_preprocess_fwd)
   uint32_t* tables;     // with tile_hist: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
   uint32_t tables_words;
   unsigned long long* ready;  // ImgView::ready

@@ -8,6 +8,7 @@
 // not: plain scalar algebra on registers (glm is not used), K9 and K10 fused so every per-Gaussian
 // array is touched once, outputs written unconditionally so no pre-zeroing pass is needed.
 #include "mgs_common.h"
+#include <algorithm>
 #include "mgs_device.h"
 
 namespace mgs {
@@ -132,8 +133,20 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       return;
     }
   }
+  // HIST launches a.zero_blocks more workgroups at the END of the grid that only zero the later backward's accumulator block
+  // (17 MB at BASELINE configs[2]).  The working workgroups used to issue those stores first thing "on the side" -- but loads
+  // and stores share one in-order counter, so their first wait for a load was also a wait for every store before it; and at
+  // 100 000 Gaussians 98 working workgroups leave 158 CUs idle for the job.
+  const int nwork = HIST ? (int)gridDim.x - 1 - a.zero_blocks : (int)gridDim.x;
+  if constexpr (HIST) {
+    if ((int)blockIdx.x > nwork) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const size_t zb = (size_t)((int)blockIdx.x - nwork - 1);
+      for (size_t i = zb * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)a.zero_blocks * blockDim.x) a.zero_ptr[i] = z;
+      return;
+    }
+  }
   const int blk = HIST ? (int)blockIdx.x - 1 : (int)blockIdx.x;  // working workgroup
-  const int nwork = HIST ? (int)gridDim.x - 1 : (int)gridDim.x;
   // Workgroups never straddle views: view = blockIdx / (workgroups per view), so the camera is wave-uniform.
   // Single view (V == 1): gi == idx and everything below is the plain per-Gaussian preprocess.
   const int bpv = (a.Pg + (int)blockDim.x - 1) / (int)blockDim.x;
@@ -141,7 +154,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const int gi = (blk - v * bpv) * (int)blockDim.x + (int)threadIdx.x;  // Gaussian
   const int idx = v * a.Pg + gi;                                                    // (virtual) instance owner
   const int Tv = a.tiles_x * a.tiles_y, T = Tv * a.V;
-  if (a.zero_ptr) {  // fire-and-forget stores: they drain while the projection math runs
+  if (a.zero_ptr && (!HIST || a.zero_blocks == 0)) {  // (the rocPRIM binning path: on the side, as before)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)nwork * blockDim.x)
       a.zero_ptr[i] = z;
@@ -328,10 +341,13 @@ hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {  // p 4-byt
 
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  if (a.tile_hist)
-    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK) + 1), dim3(PRE_BLOCK),
-                       sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, a, g, radii);
-  else
+  if (a.tile_hist) {
+    FwdPreArgs b = a;
+    // one zeroing workgroup per 16 K float4 (16 stores per thread), at most 128
+    b.zero_blocks = b.zero_ptr ? (int)std::min<size_t>(128, (b.zero_f4 + 16383) / 16384) : 0;
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK) + 1 + b.zero_blocks),
+                       dim3(PRE_BLOCK), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, b, g, radii);
+  } else
     hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.Pg + 255) / 256), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();
 }
