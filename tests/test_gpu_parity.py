@@ -154,6 +154,18 @@ def test_kernel_variants_agree_with_oracle(name):
             _lib.set_option(k, v)
 
 
+@pytest.mark.parametrize("P", [520, 700, 1030, 1300, 1540, 2100, 2570, 4100])
+def test_merge_rank_search_over_segment_lengths(P):
+    """One tile, 512-key segments: the tile's list is cut into 2..8 segments of many different lengths (powers of two, one
+    more, one less, a short last segment) and every key is ranked in the others by the bounded branch-free search of
+    bin_merge_emit_kernel; the sorted order must be the oracle's (images and gradients follow from it)."""
+    try:
+        _lib.set_option("seg", 512)
+        _check(dict(P=P, F=3, W=16, H=16, neg=False))
+    finally:
+        _lib.set_option("seg", _DEFAULTS["seg"])
+
+
 def _raw_forward(d, kwd, P, F, W=128, H=128):
     from manigaussian_amd import _C
     e = torch.Tensor([])
