@@ -216,6 +216,19 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   __shared__ uint32_t total;
   const int tid = threadIdx.x;
   const bool tables = (int)blockIdx.x == nblk;
+  // Everything this thread reads from memory is requested NOW, in one batch: the kernel is a chain of round trips otherwise
+  // (instance count -> histogram -> reservation row -> rect -> depth: five, each ~0.7 us of a 6.8 us kernel).
+  // Same (view, Gaussian) partition as the forward preprocess: workgroups never straddle views.
+  const int bpv = (Pg + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int v = (int)blockIdx.x / bpv;
+  const int gi = ((int)blockIdx.x - v * bpv) * PRE_BLOCK + tid;
+  const bool work = !tables && gi < Pg;
+  const int idx = work ? v * Pg + gi : 0;  // (virtual) instance owner
+  const uint2 r_pre = rect[idx];
+  const float depth_pre = depths[idx];
+  const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * T;
+  const uint32_t hist_pre = tile_hist[tid < T ? tid : 0];
+  const uint32_t row_pre = tables ? 0u : row[tid < T ? tid : 0];
   const uint32_t R = flags[FLAG_NUM_RENDERED];
   if (tables && tid == 0 && ready) *ready = 0ull;  // the preprocess's hand-shake word: "not ready" for the next launch on this buffer
   if (tables && tid == 0 && host_status)  // report {tag, flags, R} to the host (mapped pinned memory)
@@ -229,11 +242,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
     }
     return;
   }
-  const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * S;
   for (int t = tid; t < S; t += blockDim.x) {
-    s_start[t] = tile_hist[t];
+    const bool first = t == tid;  // (the first PRE_BLOCK tiles came with the batch above)
+    s_start[t] = first ? hist_pre : tile_hist[t];
     s_cnt[t] = 0;
-    s_base[t] = tables ? 0u : row[t];  // only entries of slices this workgroup contributed to are meaningful
+    s_base[t] = first ? row_pre : (tables ? 0u : row[t]);  // only entries of slices this workgroup contributed to are meaningful
   }
   __syncthreads();
   block_exclusive_scan(s_start, S, tmp, &total);
@@ -252,17 +265,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
     if (tid == 0) seg_base[S] = total;
     return;
   }
-  // same (view, Gaussian) partition as the forward preprocess: workgroups never straddle views
-  const int bpv = (Pg + PRE_BLOCK - 1) / PRE_BLOCK;
-  const int v = (int)blockIdx.x / bpv;
-  const int gi = ((int)blockIdx.x - v * bpv) * PRE_BLOCK + tid;
-  if (gi >= Pg) return;
-  const int idx = v * Pg + gi;  // (virtual) instance owner
-  const uint2 r = rect[idx];
+  if (!work) return;
+  const uint2 r = r_pre;
   const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16);
   const int y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
   if (x1 <= x0 || y1 <= y0) return;
-  const float depth = depths[idx];
+  const float depth = depth_pre;
   const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) {
@@ -394,11 +402,11 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   // one XCD, the runs round-robin over the XCDs (a contiguous eighth of the list per XCD is unbalanced: dense tiles are
   // neighbours).  With the identity map the 7 segments of a configs[4] tile ran on 7 XCDs and the kernel fetched 296 MB for
   // 29 MB of keys (FETCH_SIZE, profiles/r02_sq_counters_c5shape.json).
-  const uint32_t nseg = *n_seg;
   const uint32_t xj = blockIdx.x >> 3;
   const uint32_t seg_i = ((xj >> 3) * 8u + (blockIdx.x & 7u)) * 8u + (xj & 7u);
+  const uint4 d = seg_desc[seg_i];  // surplus workgroups read an unused (in-bounds: the table has gridDim.x entries) entry
+  const uint32_t nseg = *n_seg;     // ... in the same round trip as the count that tells them so
   if (seg_i >= nseg) return;
-  const uint4 d = seg_desc[seg_i];
   const uint32_t cnt = d.y, start = d.z, L = d.w;
   if (cnt == L) return;  // single-segment slice: bin_segsort_kernel wrote its ids already
   const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);

@@ -79,7 +79,7 @@ struct BinView {
   uint64_t* keys_unsorted;  // [R]  (depth bits << 32 | id), tile-major, unordered inside a tile  (rocPRIM: tile<<32|depth)
   uint64_t* keys;           // [R]  segment-sorted keys                                            (rocPRIM: sorted keys)
   uint32_t* point_list;     // [R]  sorted Gaussian ids
-  uint4* seg_desc;          // [R/SEG_MIN + T + 2]  segment -> {first key, count, tile slice start, tile slice length}
+  uint4* seg_desc;          // [R/SEG_MIN + T + 66] segment -> {first key, count, tile slice start, tile slice length}
   // rocPRIM binning only; ALIASES the render state below (dead before the render forward starts writing it)
   uint32_t* vals_unsorted;  // [R]
   void* sort_temp;
@@ -167,7 +167,7 @@ inline BinView carve_binning(void* p, int R, int T, int F, uint32_t pool, ChunkV
   b.keys_unsorted = c.take<uint64_t>(Ra);
   b.keys = c.take<uint64_t>(Ra);
   b.point_list = c.take<uint32_t>(Ra);
-  b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)T + 2);
+  b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)T + 66);  // (+64: the merge kernel's grid is rounded up to 64 and every workgroup reads its entry)
   c.off = align_up(c.off);
   const size_t alias0 = c.off;  // everything below is written by the render forward, i.e. after the binning is done
   ChunkView v;
