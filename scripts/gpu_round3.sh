@@ -23,7 +23,7 @@ print(c['name'], c['P'], f\"{c['W']}x{c['H']}\", 'renders/gpu', c['renders_per_s
       round(j['value'] / 1e6, 1), 'M/s', 'long_run', round(lr.get('ms_per_step', 0), 4), 'modes', {k: round(v, 4) for k, v in j['modes_ms_per_step'].items()},
       'errors', j.get('mode_errors'), 'roof', round(j['roofline']['frac'], 3), 'stages', {k: round(v, 4) for k, v in j['stages_ms'].items() if v})
 "; }
-for W in tests quick bench configs stats stats_dyn pmc variants trace; do
+for W in tests quick configs stats stats_dyn pmc bench variants trace; do
   want "$@" || continue
   case $W in
   tests)
@@ -69,7 +69,9 @@ for W in tests quick bench configs stats stats_dyn pmc variants trace; do
       echo "pmc pass $i ($grp) rc=$?"
       find $OUT/pmc_$i -name "*kernel_trace.csv" -size +4M -delete
     done
-    python scripts/sq_counters.py $OUT/sq_counters.json $H $OUT/pmc_1 $OUT/pmc_2 $OUT/pmc_3 $OUT/pmc_4 $OUT/pmc_5 $OUT/pmc_6 ;;
+    python scripts/sq_counters.py $OUT/sq_counters.json $H $OUT/pmc_1 $OUT/pmc_2 $OUT/pmc_3 $OUT/pmc_4 $OUT/pmc_5 $OUT/pmc_6
+    # a bench section that follows in the same call prints these counters as `traffic` (same binary: bench.py checks the build id)
+    [ -z "$PMC_BENCH_ARGS" ] && cp $OUT/sq_counters.json profiles/r03_sq_counters.json ;;
   variants)
     cp manigaussian_amd/libmgsplat.so /tmp/libmgsplat_keep.so
     for so in manigaussian_amd/variants/libmgsplat_*.so; do
