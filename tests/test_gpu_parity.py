@@ -90,6 +90,26 @@ def test_translucent_scene_walks_many_rounds(F):
         assert fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7, f"grad {k} (threshold-fragile): {fragile:.3e} vs {mag:.3e}"
 
 
+def test_one_block_with_hundreds_of_chunks():
+    """One 8x8 image = one block; 40 000 Gaussians whose opacity sits just above 1/255, so that each is blended at a pixel or
+    two and nothing terminates: the block's list holds > 400 chunks of 64 survivors -- dozens of forward rounds (more than
+    the 16 / 8 whose first records the kernels keep in LDS: the chunk-record lookups fall back to the table in memory) and
+    more q values than fit the backward's LDS area (the sums behind a chunk then come from memory)."""
+    sc, cam, kw, dC, dF = util.scene_case(P=40000, F=32, W=8, H=8)
+    sc["opacities"] = torch.full_like(sc["opacities"], 0.0045)
+    cr, fr, rr, gr, st = util.run_oracle_b(sc, kw, dC, dF)
+    assert st.num_rendered > 26000 and float(st.array("final_T").min()) > 1e-3, (st.num_rendered, float(st.array("final_T").min()))
+    ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, True, (0.1, 0.2, 0.3))
+    assert torch.equal(rh, rr)
+    for a, b in ((ch, cr), (fh, fr)):
+        robust, fragile, frac = util.image_errors(a, b, st)
+        assert robust <= IMG_TOL and fragile <= util.FRAGILE_TOL
+    errs, _ = util.grad_errors_split(gh, gr, st)
+    for k, (robust, fragile, mag) in errs.items():
+        assert robust <= GRAD_TOL * mag + 1e-7, f"grad {k}: err {robust:.3e} vs max {mag:.3e}"
+        assert fragile <= util.FRAGILE_GRAD_TOL * mag + 1e-7, f"grad {k} (threshold-fragile): {fragile:.3e} vs {mag:.3e}"
+
+
 def test_randomised_sweep_fixed_seed():
     """24 cases of tests/tools/fuzz_parity.py (random sizes, feature widths, colour sources, opacity scales, cameras)."""
     import importlib.util
