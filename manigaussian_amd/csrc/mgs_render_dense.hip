@@ -119,6 +119,9 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   uint32_t round = 0;
 
   const bool allocator = tid == (NW - 1) * 64;  // lane 0 of the last wave takes the rounds' chunk records from the pool
+  // (workgroup- and grid-uniform) grids of at most 1024 blocks whose pool holds a first round for every block
+  const bool static0 = (uint32_t)nblocks <= 1024u && (uint32_t)nblocks * (uint32_t)NW <= pool;
+  const uint32_t dyn_base = static0 ? (uint32_t)nblocks * (uint32_t)NW : 0u;  // the atomically taken records lie behind the slices
   for (;; round++) {
     // (lane-derived indices pass through an opaque asm once per round: otherwise the compiler hoists the address arithmetic
     //  of every unrolled LDS / global access below out of the round loop and spills it: 152 bytes of scratch per lane)
@@ -129,7 +132,13 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     // returning atomic's round trip hides behind it.
     uint32_t b0 = 0;
     const bool more = next < rng.y || qtail > qhead;
-    if (allocator && more) b0 = atomicAdd(&flags[FLAG_CHUNKS_USED], (uint32_t)NW);
+    if (allocator && more) {
+      // (round 0 of a small grid: a fixed slice of the pool, no atomic.  At 128 x 128 every one of the 256 blocks asked
+      //  for its first records at the same moment, 256 returning atomics on ONE address: the L2 serves those one after
+      //  the other, and the last block got its answer ~15 k cycles later -- the whole "fill" phase of the timeline)
+      if (static0 && round == 0) b0 = ((uint32_t)tile * 4u + (uint32_t)sub) * (uint32_t)NW;
+      else b0 = dyn_base + atomicAdd(&flags[FLAG_CHUNKS_USED], (uint32_t)NW);
+    }
     // ---- fill: examine FILLK * FSTEP entries per step until a full round of survivors waits (or the list ends);
     //      survivors go, in list order, to this block's list in memory (read back below and by the backward) ----
     while (qtail - qhead < ROUND && next < rng.y) {
@@ -528,7 +537,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       nsurv[(size_t)tile * 4 + sub] = make_uint2(qtail, round > 0 || vis > 0 ? rb_hist[0] : 0u);  // + round 0's first record
       // the workgroup that drew the last ticket reports {tag, overflow, chunk records used} to the host (mapped pinned memory)
       if (ticket == (uint32_t)nblocks && host_status) {
-        const uint32_t used = __hip_atomic_load(&flags[FLAG_CHUNKS_USED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t used = dyn_base + __hip_atomic_load(&flags[FLAG_CHUNKS_USED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t ovf = (__hip_atomic_load(&flags[FLAG_PREFILTERED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) & 1u;
         __hip_atomic_store(host_status + 1, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)ovf << 32) | used,
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
