@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 5
+#define MGS_ABI_VERSION 6
 
 /* error codes */
 #define MGS_OK 0
@@ -180,7 +180,8 @@ int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int3
  *   dL_dmeans2D [P,3] (NDC units, z = 0), dL_dopacity [P,1], dL_dcolors [P,3], dL_dfeature [P,F],
  *   dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4],
  *   dL_dconic [P,4] (optional, may be NULL; reference keeps it internal).
- * scratch: >= mgs_backward_scratch_bytes(P, M, F) device bytes, contents undefined on entry. */
+ * scratch: >= mgs_backward_scratch_bytes(P, M, F) device bytes, contents undefined on entry.
+ * a->language_feature must be 16-byte aligned (feature rows are read as float4; MGS_ERR_INVALID_ARG otherwise). */
 /* num_rendered: the forward's count, or -1 if the caller has not looked yet (asynchronous forward). */
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
                            const float* dL_dout_color, const float* dL_dout_feature, float* dL_dmeans2D,
@@ -294,6 +295,13 @@ int mgs_novel_calib_host(int V, const float* c2w, const float* K, int W, int H, 
 int mgs_profile_num_stages(void);
 const char* mgs_profile_stage_name(int stage);
 int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
+
+/* Diagnostic, BLOCKING (one small device->host copy + a stream synchronise): what the forward that last ran on a's
+ * workspaces left for its backward -- *incidences = (8x8 pixel block, Gaussian) pairs its fills kept, *chunks = the
+ * 64-survivor chunks they make.  V = 0: a single-view forward, V > 0: a batch of V views.  bench.py prices the render
+ * kernels' HBM traffic with them (the reference's dataflow has no such state: RAST/cuda_rasterizer/backward.cu:399-593
+ * walks the tile lists again). */
+int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, mgs_stream_t stream);
 
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */

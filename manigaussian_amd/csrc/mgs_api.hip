@@ -60,10 +60,11 @@ static bool supported_F(int F) {
 
 // ---- per-stage timing with hipEvents on the caller's stream (mgs_set_option("profile", 1|2)) ----
 enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_BWD_MEMSET, ST_RENDER_BWD,
-             ST_PREPROCESS_BWD, ST_COUNT };
+             ST_PREPROCESS_BWD, ST_BIN_SCATTER, ST_BIN_SEGSORT, ST_BIN_MERGE, ST_COUNT };
+// (scan / duplicate_with_keys / binning_sort / ranges_gather: the rocPRIM binning; bin_*: the three kernels of the default one)
 static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_with_keys", "binning_sort",
                                                   "ranges_gather", "render_fwd", "bwd_memset", "render_bwd",
-                                                  "preprocess_bwd"};
+                                                  "preprocess_bwd", "bin_scatter", "bin_segsort", "bin_merge"};
 struct Profiler {
   std::mutex mu;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> used[ST_COUNT];
@@ -253,6 +254,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   segsort = segsort_binning(o, p.tiles_x * p.tiles_y);
   if (!segsort) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");  // (else: the preprocess does it)
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
+  im.nonce = segsort ? p.nonce : 0ull;
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -274,14 +276,22 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
 }
 
 // Blocking read-back of {instance count, flags} (the reference's cudaMemcpy, rasterizer_impl.cu:284).
-static int read_count_blocking(const GeomView& g, int P, bool segsort, hipStream_t stream, uint32_t* R, uint32_t* fl) {
+static const char* const kHandshakeMsg =
+    "the forward preprocess gave up waiting for its zeroed tile tables (a workgroup of the launch did not make progress for "
+    "about a second): nothing was binned for this call";
+static int read_count_blocking(const GeomView& g, const ImgView& im, int P, bool segsort, hipStream_t stream, uint32_t* R,
+                               uint32_t* fl) {
   uint32_t host[2] = {0, 0};
+  unsigned long long mark = 0ull;
+  if (segsort && im.nonce)
+    MGS_HIP(hipMemcpyAsync(&mark, im.ready + 1, sizeof(mark), hipMemcpyDeviceToHost, stream), "hand-shake read-back");
   MGS_HIP(hipMemcpyAsync(&host[0], segsort ? g.flags + FLAG_NUM_RENDERED : g.point_offsets + (P - 1), sizeof(uint32_t),
                          hipMemcpyDeviceToHost, stream), "num_rendered read-back");
   MGS_HIP(hipMemcpyAsync(&host[1], g.flags + FLAG_PREFILTERED, sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
           "flag read-back");
   MGS_HIP(hipStreamSynchronize(stream), "stream sync");
   *R = host[0]; *fl = host[1];
+  if (segsort && im.nonce && mark == im.nonce) { set_error("%s", kHandshakeMsg); return MGS_ERR_HIP; }
   return MGS_OK;
 }
 
@@ -310,6 +320,7 @@ static int wait_status(uint64_t* host_status, uint32_t tag, hipStream_t stream, 
 }
 
 static int check_prefiltered(uint32_t fl) {
+  if (fl & 2u) { set_error("%s", kHandshakeMsg); return MGS_ERR_HIP; }  // (status-word flag of the bin scatter kernel)
   if (fl & 1u) {
     set_error("Point is filtered although prefiltered is set. This shouldn't happen!");  // auxiliary.h:158
     return MGS_ERR_INVALID_ARG;
@@ -335,13 +346,14 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
 // Binning + render.  R: instance count if the host knows it (the rocPRIM binning needs it), else -1.
 // status: where the device reports (see StatusSink), host == nullptr: nowhere.
 static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const int32_t* radii, float* out_color,
-                          float* out_feature, StatusSink status, hipStream_t stream) {
+                          float* out_feature, StatusSink status, unsigned long long nonce, hipStream_t stream) {
   const int F = a->include_feature ? a->F : 0;
   const int T = num_tiles(a->W, a->H);
   const bool segsort = segsort_binning(o, T);
   GeomView g = carve_geom(a->geom, a->P, a->M, T, 1, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
+  im.nonce = nonce;  // (0: the caller has already looked at the preprocess's outcome)
   const BinShape bs = bin_shape(a, T, F);
   if (!a->binning || bs.cap < 0 || (R >= 0 && R > bs.cap)) {
     set_error("binning workspace too small: %zu bytes hold %d instances, need %d", a->binning_bytes, bs.cap, R);
@@ -351,9 +363,11 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   if (segsort) {
-    StageTimer t(ST_SORT, stream);
-    MGS_STAGE(launch_bin_segsort(g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
-              "segment-sort binning", a->debug, stream);
+    for (int k = 0; k < 3; k++) {
+      StageTimer t(ST_BIN_SCATTER + k, stream);
+      MGS_STAGE(launch_bin_segsort(k, g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
+                "segment-sort binning", a->debug, stream);
+    }
   } else {
     { StageTimer t(ST_DUPLICATE, stream);
       MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, o.tight_bins, stream),
@@ -398,7 +412,7 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
-  rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
+  rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl);
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
@@ -425,7 +439,7 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t R, const int32_
     ImgView im = carve_img(a->img, a->W, a->H, nullptr);
     MGS_HIP(launch_zero_bytes(im.flags + FLAG_CHUNKS_USED, 2 * sizeof(uint32_t), stream), "reset render counters");
   }
-  return enqueue_render(a, options_of(a), R, radii, out_color, out_feature, StatusSink{nullptr, 0}, stream);
+  return enqueue_render(a, options_of(a), R, radii, out_color, out_feature, StatusSink{nullptr, 0}, 0ull, stream);
 }
 
 int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_color, float* out_feature,
@@ -455,7 +469,7 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   if (!segsort || !host_status || a->debug) {
     // no device->host status channel: read back (blocking) like the two-call path
     if (a->async_forward) { set_error("async_forward needs host_status, the segment-sort binning and debug == 0"); return MGS_ERR_INVALID_ARG; }
-    rc = read_count_blocking(g, a->P, segsort, stream, &R, &fl);
+    rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl);
     if (rc) return rc;
     rc = check_prefiltered(fl);
     if (rc) return rc;
@@ -468,13 +482,13 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
       hs[1] = kStatusPending;
       hs[0] = ((uint64_t)(a->status_tag & 0xffffu) << 48) | ((uint64_t)(fl & 0xffffu) << 32) | R;
     }
-    return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, stream);
+    return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, 0ull, stream);
   }
   // sync-free: everything is enqueued; the binning kernel stores {tag, flags, R} to the mapped host word as soon as the
   // preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
   volatile uint64_t* hs = host_status;
   hs[0] = kStatusPending; hs[1] = kStatusPending;
-  rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, stream);
+  rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, im.nonce, stream);
   if (rc) return rc;
   if (a->async_forward) { *num_rendered = -1; return MGS_OK; }  // the caller reads mgs_forward_result later
   rc = wait_status(host_status, a->status_tag, stream, &R, &fl);
@@ -532,6 +546,10 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
       !a->binning) {
     set_error("backward: workspace too small");
     return MGS_ERR_WORKSPACE;
+  }
+  if (F > 0 && (reinterpret_cast<uintptr_t>(a->language_feature) & 15u)) {  // the render backward reads feature rows as float4
+    set_error("backward: language_feature must be 16-byte aligned");
+    return MGS_ERR_INVALID_ARG;
   }
   const Options o = options_of(a);
   const int T = num_tiles(a->W, a->H);
@@ -713,14 +731,17 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   }
   p.tile_hist = im.tile_hist; p.blk_base = g.blk_base;
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
+  im.nonce = p.nonce;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;
   hs[0] = kStatusPending; hs[1] = kStatusPending;
   const StatusSink status = {host_status, a->status_tag};
-  { StageTimer t(ST_SORT, stream);
-    MGS_HIP(launch_bin_segsort(g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
-            "segment-sort binning (views)"); }
+  for (int k = 0; k < 3; k++) {
+    StageTimer t(ST_BIN_SCATTER + k, stream);
+    MGS_HIP(launch_bin_segsort(k, g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
+            "segment-sort binning (views)");
+  }
   const RenderArgs r = views_render_args(a, o, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);
     MGS_HIP(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, status, stream), "render forward (views)"); }
@@ -754,6 +775,10 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
   if (!radii || !dL_dout_color || !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D ||
       !dL_dscales || !dL_drotations || (a->M > 0 && !dL_dsh) || (F > 0 && (!dL_dfeature || !dL_dout_feature))) {
     set_error("backward (views): a required pointer is NULL");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if (F > 0 && (reinterpret_cast<uintptr_t>(a->language_feature) & 15u)) {
+    set_error("backward (views): language_feature must be 16-byte aligned");
     return MGS_ERR_INVALID_ARG;
   }
   const Options o = options_of(a);
@@ -809,6 +834,27 @@ int mgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
   if (P == 0) return MGS_OK;
   if (!means3D || !viewmatrix || !projmatrix || !present) { set_error("mark_visible: NULL pointer"); return MGS_ERR_INVALID_ARG; }
   MGS_HIP(launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, stream), "mark_visible");
+  return MGS_OK;
+}
+
+// Diagnostic (blocking): what the forward that last ran on these workspaces left behind -- the (8x8 block, Gaussian)
+// incidences its fills found and the 64-survivor chunks they make (the unit of the forward -> backward state).
+int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, mgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a || !a->binning || V < 0 || V > MAX_VIEWS) { set_error("forward_stats: bad argument"); return MGS_ERR_INVALID_ARG; }
+  const int F = a->include_feature ? a->F : 0;
+  const int T = V > 0 ? atlas_of(a->W, a->H, V).T : num_tiles(a->W, a->H);
+  const BinShape bs = bin_shape(a, T, F);
+  if (bs.cap < 0) { set_error("forward_stats: binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  ChunkView cv;
+  (void)carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
+  std::vector<uint2> h((size_t)T * 4);
+  MGS_HIP(hipMemcpyAsync(h.data(), cv.nsurv, h.size() * sizeof(uint2), hipMemcpyDeviceToHost, stream), "forward_stats copy");
+  MGS_HIP(hipStreamSynchronize(stream), "forward_stats sync");
+  int64_t inc = 0, ch = 0;
+  for (const uint2& v : h) { inc += v.x; ch += (v.x + CHUNK - 1) / CHUNK; }
+  if (incidences) *incidences = inc;
+  if (chunks) *chunks = ch;
   return MGS_OK;
 }
 

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
                                                                 uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ seg_base,
                                                                 uint4* __restrict__ seg_desc,
-                                                                unsigned long long* ready) {
+                                                                unsigned long long* ready, unsigned long long nonce) {
   extern __shared__ uint32_t lds_u[];
   const int S = T;
   uint32_t* s_start = lds_u;          // [S] exclusive scan of the histogram
@@ -229,12 +229,16 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   const uint32_t* __restrict__ row = blk_base + (size_t)blockIdx.x * T;
   const uint32_t hist_pre = tile_hist[tid < T ? tid : 0];
   const uint32_t row_pre = tables ? 0u : row[tid < T ? tid : 0];
-  const uint32_t R = flags[FLAG_NUM_RENDERED];
+  // ready[1] == this forward's nonce: a preprocess workgroup gave up waiting for the zeroed tables (see there).  The
+  // histogram is then incomplete: nothing is binned, and flag bit 1 (MGS_FLAG_HANDSHAKE) tells the host why.
+  const bool hs_failed = ready != nullptr && nonce != 0ull && ready[1] == nonce;
+  const uint32_t R = hs_failed ? 0xffffffffu : flags[FLAG_NUM_RENDERED];
   if (tables && tid == 0 && ready) *ready = 0ull;  // the preprocess's hand-shake word: "not ready" for the next launch on this buffer
   if (tables && tid == 0 && host_status)  // report {tag, flags, R} to the host (mapped pinned memory)
-    __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)(flags[FLAG_PREFILTERED] & 0xffffu) << 32) | R,
+    __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) |
+                       ((uint64_t)((flags[FLAG_PREFILTERED] & 0xfffdu) | (hs_failed ? 2u : 0u)) << 32) | (hs_failed ? 0u : R),
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (R > capacity) {  // the workspace cannot hold the lists: publish "nothing binned", the caller retries
+  if (R > capacity) {  // the workspace cannot hold the lists (or the hand-shake failed): publish "nothing binned", the caller retries
     if (tables) {
       for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(0u, 0u);
       for (int t = tid; t < S; t += blockDim.x) seg_base[t] = 0u;
@@ -457,28 +461,33 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
 }
 
 template <int SEGN>
-static void launch_sort_merge(const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
+static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
-  hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                     b.keys_unsorted, b.keys, b.point_list);
-  hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / 2), 0, s, im.seg_base + T,  // (XCD map)
-                     b.seg_desc, b.keys, b.point_list);
+  if (which == 1)
+    hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
+                       b.keys_unsorted, b.keys, b.point_list);
+  else
+    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / 2), 0, s, im.seg_base + T,  // (XCD map)
+                       b.seg_desc, b.keys, b.point_list);
 }
 
-hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
+hipError_t launch_bin_segsort(int which, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
                               int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
   const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
-  // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
-                     tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, g.rect, g.depths,
-                     im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready);
+  if (which == 0) {
+    // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
+                       tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, g.rect, g.depths,
+                       im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready, im.nonce);
+    return hipGetLastError();
+  }
   switch (seg) {
-    case 512: launch_sort_merge<512>(b, im, R, T, s); break;
-    case 1024: launch_sort_merge<1024>(b, im, R, T, s); break;
-    default: launch_sort_merge<2048>(b, im, R, T, s); break;
+    case 512: launch_sort_or_merge<512>(which, b, im, R, T, s); break;
+    case 1024: launch_sort_or_merge<1024>(which, b, im, R, T, s); break;
+    default: launch_sort_or_merge<2048>(which, b, im, R, T, s); break;
   }
   return hipGetLastError();
 }

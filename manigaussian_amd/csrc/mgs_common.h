@@ -72,7 +72,8 @@ struct ImgView {
   // Hand-shake word of the forward preprocess (segment-sort binning): workgroup 0 zeroes the block above and then stores
   // the launch's nonce here; every workgroup waits for the nonce before its first atomic on the block; the bin scatter
   // kernel (next in the chain) stores 0 again.  Replaces a separate zero-fill launch per forward.
-  unsigned long long* ready;
+  unsigned long long* ready;   // [2]: [0] the hand-shake word, [1] = the launch's nonce if a workgroup gave up waiting for it
+  unsigned long long nonce;    // host side only: the nonce of the forward in flight on this workspace (0: none)
 };
 
 struct BinView {
@@ -149,6 +150,7 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.seg_base = v.flags ? v.tile_hist + S : nullptr;
   v.zero_bytes = nz * sizeof(uint32_t);
   v.ready = c.take<unsigned long long>(2);
+  v.nonce = 0ull;
   if (total) *total = c.total();
   return v;
 }
@@ -261,7 +263,9 @@ hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
 struct StatusSink { uint64_t* host; uint32_t tag; };
 // bin_mode 1: scatter -> segment sort -> rank merge
 unsigned long long next_nonce();  // process-wide counter (never 0) mixed with a per-process random word
-hipError_t launch_bin_segsort(const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
+// (three launches, issued one by one so that the stage timers of mgs_api.hip see each kernel: `which` = 0 scatter, 1 segment
+//  sort, 2 rank merge)
+hipError_t launch_bin_segsort(int which, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
                               int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
 hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
                             int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);

@@ -117,8 +117,8 @@ template <bool HIST>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ uint32_t s_hist[];  // [tiles] when HIST: instances per tile
-  __shared__ uint32_t s_total, s_pref;
-  if (HIST && threadIdx.x == 0) { s_total = 0; s_pref = 0; }
+  __shared__ uint32_t s_total, s_pref, s_fail;
+  if (HIST && threadIdx.x == 0) { s_total = 0; s_pref = 0; s_fail = 0; }
   // HIST launches ONE EXTRA workgroup, index 0, that only zeroes the forward's small tables (flags | tile histogram | segment
   // bases) and publishes the launch's nonce; the working workgroups 1 .. n wait for the nonce right before their first atomic
   // on the tables, at the very end of the kernel -- ten microseconds later.  (Workgroups are dispatched in index order, so
@@ -292,16 +292,24 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     if (touched) atomicAdd(&s_total, touched);
     if (threadIdx.x == 0) {  // the tables are zero once workgroup 0 has published this launch's nonce
-      // (workgroup 0 is dispatched first and needs ~2 us; the bound turns a wait that can never end -- a device that lost the
-      //  store -- into a failed launch the host reports, after about a second, instead of a hung queue)
+      // (workgroup 0 is dispatched first and needs ~2 us.  The wait is BOUNDED: if the nonce has not come after about a
+      //  second -- workgroup 0 held by a debugger, a device that lost the store -- this workgroup gives up WITHOUT touching
+      //  the tables and leaves the launch's nonce in ready[1]; the bin scatter kernel, next in the chain, then publishes
+      //  "nothing binned" and reports the failure through the status word, so that the host raises MGS_ERR_HIP for THIS
+      //  call instead of losing the HIP context to a trap)
       for (uint32_t polls = 0; seen != a.nonce; polls++) {
-        if (polls == (1u << 23)) __builtin_trap();
+        if (polls == (1u << 23)) {
+          s_fail = 1u;
+          __hip_atomic_store(a.ready + 1, a.nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
         seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (s_fail) return;
     if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[FLAG_NUM_RENDERED], s_total);
     if (threadIdx.x == 0 && s_pref) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
     // reserve this workgroup's slots inside every slice it contributes to; the bin scatter (same

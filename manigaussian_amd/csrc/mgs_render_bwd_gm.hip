@@ -147,8 +147,9 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   float4 pf_g0 = make_float4(0, 0, 0, 0), pf_g1 = make_float4(0, 0, -1.f, -1.f);
   if (pf) {
     const size_t slot0 = slot_of(c1);
-    if (c1 < lc) pf_last = last_pos[slot0 * 64 + lane];
-    pf_Tmid = T_mid[slot0 * 64 + lane];
+    // (a pixel that did not visit the chunk -- c1 >= lc -- may belong to a half block the forward wrote nothing for:
+    //  neutral values instead of whatever the record holds)
+    if (c1 < lc) { pf_last = last_pos[slot0 * 64 + lane]; pf_Tmid = T_mid[slot0 * 64 + lane]; }
     if (c1 > 0) pf_Tin = T_end[slot_of(c1 - 1u) * 64 + lane];
     const uint32_t first = c1 * (uint32_t)CH;
     const uint32_t nin = nsb > first ? min((uint32_t)CH, nsb - first) : 0u;
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
           g0 = r.rec[2 * (size_t)id_e]; g1 = r.rec[2 * (size_t)id_e + 1];
         }
         wave_lds_sync();  // the previous chunk's readers of pd/recs are done (same wave)
-        pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), T_mid[slot * 64 + lane]);
+        pd[w][lane] = make_float4(T_in, live ? B + bgT : 0.f, __uint_as_float(last), (c < lc) ? T_mid[slot * 64 + lane] : 1.0f);
         rec0[w][lane] = g0; rec1[w][lane] = g1; recid[w][lane] = id_e;
         wave_lds_sync();
       }

@@ -147,6 +147,121 @@ def test_sparse_visible_row_reduce_equals_the_dense_sum(tmp_path):
         assert torch.equal(a, b)
 
 
+# ---- the deformation MLP sharded by point (parallel.sharded_deformation) --------------------------------------------------------
+
+def _torch_assemble(lat, z, xyz, sh, rot, scale, op, feat, action):
+    """models_embed.py:258-287 in torch (the CPU stand-in for the HIP assembly kernel, which test_reference_modules.py pins
+    bit for bit against the reference module)."""
+    N = lat.shape[0]
+    parts = [lat, xyz.detach(), sh.detach()[:, 0], sh.detach()[:, 1:].reshape(N, 9), rot.detach(), scale.detach(),
+             op.detach()] + ([feat.detach()] if feat is not None else []) + [z]
+    if action is not None:
+        parts.append(action.repeat(N, 1))
+    return torch.cat(parts, -1)
+
+
+def _torch_apply(delta, xyz, rot):
+    """models_embed.py:295-299."""
+    return xyz.detach() + delta[:, :3], torch.nn.functional.normalize(rot.detach() + delta[:, 3:], dim=-1)
+
+
+def _dyn_setup(P, T, V, W=24, H=24, F=3):
+    from manigaussian_amd import synthetic as syn
+    from manigaussian_amd.deform import DeformationField
+    sc = syn.make_scene(P, F=F, M=4, seed=5)
+    torch.manual_seed(11)
+    field = DeformationField(d_latent=16, d_hidden=32)
+    with torch.no_grad():
+        for p_ in field.parameters():
+            p_.mul_(0.3)
+        for b in field.mlp.blocks:  # the reference zero-initialises fc_1 (resnetfc.py:26): give every weight a gradient path
+            b.fc_1.weight.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(7)
+    latent, zf = torch.randn(P, 16, generator=g), torch.randn(P, 39, generator=g)
+    actions = [torch.randn(1, 8, generator=g) for _ in range(T)]
+    cams = syn.circle_cameras(V, W, H, negative_focal=True)
+    views = []
+    for v, cam in enumerate(cams):
+        dC, dF = syn.make_cotangents(W, H, F, seed=20 + v)
+        views.append((types.SimpleNamespace(**syn.camera_settings_kwargs(cam, 1, True)), dC, dF))
+    return sc, field, latent, zf, actions, views
+
+
+def _dyn_step(plan, sc, field, latent_local, zf_local, actions, views, bucket):
+    """One dynamic step on this rank: for each of its timesteps the (point-sharded) MLP, then Oracle A renders of its views."""
+    from manigaussian_amd.parallel import sharded_deformation
+    from oracle import oracle_a
+    bucket.attach()
+    for t in plan.timesteps:
+        nxt = sharded_deformation(field, latent_local, zf_local, sc["means3D"], sc["shs"], sc["rotations"], sc["scales"],
+                                  sc["opacities"], action=actions[t], group=plan.group, assemble=_torch_assemble,
+                                  apply=_torch_apply)
+        loss = 0.0
+        for v in plan.views:
+            st, dC, dF = views[v]
+            c, f, _, _ = oracle_a.rasterize(nxt["xyz"], nxt["opacity"], st, shs=nxt["sh"],
+                                            language_feature=sc["language_feature"], scales=nxt["scale"], rotations=nxt["rot"])
+            loss = loss + (c * dC).sum() * (1.0 + 0.1 * t) + (f * dF).sum()
+        loss.backward()
+    return bucket.all_reduce()  # over the WORLD: every rank holds a share of every parameter's gradient
+
+
+def _dyn_worker(rank, world, port, out_dir, P, T, V):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from manigaussian_amd.parallel import DynamicPlan, GradBucket
+    sc, field, latent, zf, actions, views = _dyn_setup(P, T, V)
+    plan = DynamicPlan(T, V, rank, world)
+    lo, hi = plan.point_rows(P)
+    latent_local = latent[lo:hi].clone().requires_grad_(True)   # a LOCAL leaf: no collective for its gradient
+    bucket = GradBucket(dict(field.named_parameters()))
+    _dyn_step(plan, sc, field, latent_local, zf[lo:hi], actions, views, bucket)
+    torch.save(dict(lo=lo, hi=hi, timesteps=plan.timesteps, views=plan.views, latent_grad=latent_local.grad,
+                    params={k: p.grad.clone() for k, p in field.named_parameters()}, desc=plan.describe(P)),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,T,V,P", [(2, 1, 4, 151), (4, 2, 2, 96), (2, 2, 2, 80)],
+                         ids=["c5-like:2ranks-share-1-timestep", "4ranks-2groups", "c4-like:1-timestep-per-rank"])
+def test_point_sharded_deformation_equals_the_single_process_step(tmp_path, world, T, V, P):
+    """parallel.sharded_deformation + DynamicPlan: ranks that share a timestep split its MLP by point (all-gather of the
+    deltas, reduce-scatter of dL/d delta), render their views, all-reduce the MLP-gradient bucket.  Every MLP parameter's
+    gradient and every row of point_latent's must equal the single-process step's (all timesteps, all views, no sharding)
+    to 1e-5 of the tensor's max; a row count that does not divide (151 over 2) exercises the padded blocks."""
+    mp.start_processes(_dyn_worker, args=(world, _free_port(), str(tmp_path), P, T, V), nprocs=world, join=True,
+                       start_method="spawn")
+    sys.path.insert(0, ROOT)
+    from manigaussian_amd.parallel import DynamicPlan, GradBucket
+    sc, field, latent, zf, actions, views = _dyn_setup(P, T, V)
+    lat = latent.clone().requires_grad_(True)
+    bucket = GradBucket(dict(field.named_parameters()))
+    _dyn_step(DynamicPlan(T, V, 0, 1), sc, field, lat, zf, actions, views, bucket)
+    ref_params = {k: p.grad for k, p in field.named_parameters()}
+    got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+    covered = torch.zeros(T, P)
+    for r, g in enumerate(got):
+        for k, ref in ref_params.items():
+            scale = ref.abs().max().item()
+            assert scale > 0, f"{k}: the reference gradient is all zero -- the test would prove nothing"
+            assert (g["params"][k] - ref).abs().max().item() <= 1e-5 * scale, (r, k)
+        for t in g["timesteps"]:
+            covered[t, g["lo"]:g["hi"]] += 1
+        if world > T:  # the rank's rows of point_latent carry the complete gradient of ITS timestep ... (see below)
+            assert g["desc"]["mlp_points_per_rank"] == g["hi"] - g["lo"] < P
+            assert g["desc"]["all_gather_bytes_per_timestep"] == 28 * P
+    assert torch.equal(covered, torch.ones(T, P)), "every (timestep, point) must be evaluated by exactly one rank"
+    # point_latent: summed over the timesteps in the single-process step; a rank's local leaf holds its timesteps' share of
+    # its rows, so the ranks' contributions add up to the reference row by row
+    total = torch.zeros_like(lat.grad)
+    for g in got:
+        total[g["lo"]:g["hi"]] += g["latent_grad"]
+    assert (total - lat.grad).abs().max().item() <= 1e-5 * lat.grad.abs().max().item()
+
+
 # ---- bench.py --gpus N: the driver's command shape must launch N ranks by itself ------------------------------------------
 
 def _bench(args, timeout=600):
