@@ -25,21 +25,30 @@ Modes (all three are timed and reported under "modes_ms_per_step"; `value` comes
 EXACTLY --steps steps are timed for `value` / `ms_per_step` / `steps`.  A K-step region shorter than 50 ms is additionally
 re-measured over a longer region and reported as `long_run` (the short region carries ~0.1 ms of bracket overhead).
 
-Dynamic configs (BASELINE configs[3] / [4], strong scaling: the work of a step is fixed, the ranks share it):
+Dynamic configs (BASELINE configs[3] / [4], strong scaling: the work of a step is fixed, the ranks share it --
+manigaussian_amd.parallel.DynamicPlan):
   c4  100 000 Gaussians, DeformationField (fp32 MLP 70 -> 512 x 5 -> 7) per timestep, 4 timesteps x 4 views = 16 renders per
-      step; rank r takes a contiguous share of the (timestep, view) items (4 GPUs: one timestep x 4 views each).
-  c5  500 000 Gaussians, 256 x 256, F = 32, DeformationField, 8 views per step (8 / N views per GPU: 8, 4, 2, 1).
-  Per timestep on a rank: input assembly (HIP) -> MLP GEMMs (torch / hipBLASLt) + fused elementwise passes (HIP) -> apply
-  (HIP) -> ONE batched render of that rank's views -> l2(rgb) + 0.01 l2(feature) -> backward into the MLP parameters (a flat
-  gradient bucket: the one all-reduce when N > 1, asynchronous) and into point_latent (a local leaf, not reduced).
+      step.  N <= 4 ranks: rank r evaluates timesteps r, r + N, ... alone; N = 8: two ranks share a timestep.
+  c5  500 000 Gaussians, 256 x 256, F = 32, DeformationField, ONE timestep x 8 views per step: all N ranks share the timestep.
+  Ranks that share a timestep split its MLP BY POINT (parallel.sharded_deformation: all-gather of the [P, 7] deltas,
+  reduce-scatter of dL/d delta) and its views round-robin: the 500 000-point MLP (72 ms) is evaluated once per step across
+  the job, not once per rank.  Per timestep on a rank: input assembly (HIP) of ITS points -> MLP GEMMs (torch / hipBLASLt)
+  + fused elementwise passes (HIP) -> all-gather -> apply (HIP) -> ONE batched render of that rank's views -> l2(rgb) + 0.01
+  l2(feature) -> backward: reduce-scatter, MLP backward into the flat parameter-gradient bucket (the one all-reduce,
+  asynchronous) and into this rank's rows of point_latent (a local leaf, complete without a collective).
 
 The JSON line also carries
-  roofline      the dominant kernel (render backward) timed live with HIP events on its launch stream; what bounds it
-                (VALU issue, from the committed counter passes profiles/r02_sq_counters.json, tied to the library's
-                hash) and its HBM line: algorithmic bytes (R*(112+12F) + N_pix*(20+4F)) / duration vs
-                8 TB/s, counter bytes per launch;
+  roofline      the dominant kernel (render backward) timed live with HIP events on its launch stream, against the HBM
+                roof: `achieved` = the bytes THIS dataflow has to move per launch (every array once) / duration,
+                `traffic` = counter bytes per launch from the committed passes of the same binary, `frac` <= 1 by
+                construction (checked; --strict-roofline makes a violation fatal); beside it what actually limits the
+                kernel (VALU issue / waits) and, for reference, SURVEY.md 8d's per-instance-atomic charge (not a bound);
+  roofline_by_kernel  the same HBM line for all seven kernels of a step, counter-based fractions included;
+  roofline_mlp  (dynamic configs) the deformation MLP against the fp32 MFMA roof (157.3 TFLOP/s): FLOPs and time of its
+                forward + backward, measured apart from the rasterizer;
   cpu_baseline  Oracle B (oracle/mgs_oracle.c, a port: the reference has no CPU rasterizer) on the host cores, same
-                workload, a bounded number of fwd+bwd passes.
+                workload, a bounded number of fwd+bwd passes; dynamic configs: + the MLP in torch on the same cores over a
+                bounded sample of points.
 """
 import argparse
 import hashlib
@@ -55,6 +64,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU)
 VALU_PEAK_GIPS = 1228.8   # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide)
 MIN_TIMED_MS = 50.0       # a timed region shorter than this is re-measured over a longer one, reported beside it (`long_run`)
 EXTRA_WARMUP_MS = 30.0    # untimed steps beyond --warmup until the device has been busy this long (clock ramp)
@@ -95,6 +105,11 @@ def parse():
                     help="static configs, N > 1: 'sparse' reduces only the rows of Gaussians some rank saw (radii > 0): "
                          "parallel.sparse_all_reduce_grads -- one host read of the row count per step")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
+    ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
+                    help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
+                         "host-device synchronisation: what graph capture needs); 'safe' is the package default")
+    ap.add_argument("--strict-roofline", action="store_true", help="exit non-zero if a printed roofline fraction exceeds 1")
     ap.add_argument("--calibrate", action="store_true", help="counter passes: launch the library's known-instruction-mix "
                                                              "kernel a few times first (scripts/sq_counters.py checks it)")
     return ap.parse_args()
@@ -138,6 +153,35 @@ def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds):
                       f"{best * 1e3:.1f} ms, OpenMP {cores} threads"}
 
 
+def cpu_baseline_dynamic(syn, sc, cam, d_color, d_feat, P, timesteps, renders_total, max_seconds):
+    """Dynamic configs on the host cores: the deformation MLP in torch (same module, plain path, fwd + bwd) over a bounded
+    SAMPLE of points, scaled linearly to P (the MLP is independent per point), plus Oracle B for one render of the full set;
+    the step = timesteps x MLP + renders_total x render."""
+    import torch
+    from manigaussian_amd.deform import ResnetFC
+    rast = cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds * 0.5)
+    t_render = P / rast["value"]
+    n = min(P, 20000)
+    mlp = ResnetFC(70)
+    x = torch.randn(n, 128 + 70, requires_grad=True)
+    times, t_start = [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        delta, _ = mlp(x)
+        delta.sum().backward()
+        times.append(time.perf_counter() - t0)
+        mlp.zero_grad(set_to_none=True)
+        x.grad = None
+        if len(times) >= 4 or time.perf_counter() - t_start > max_seconds * 0.5:
+            break
+    t_mlp = min(times) * (P / n)
+    t_step = timesteps * t_mlp + renders_total * t_render
+    return {"value": P * renders_total / t_step, "unit": "Gaussians/s", "cores": rast["cores"], "kind": "port",
+            "sample": f"MLP (torch CPU, {torch.get_num_threads()} threads): {len(times)} fwd+bwd passes over {n} of {P} points, "
+                      f"best {min(times) * 1e3:.0f} ms, scaled by P/{n} -> {t_mlp * 1e3:.0f} ms per timestep; rasterizer: "
+                      f"{rast['sample']}; step = {timesteps} x MLP + {renders_total} x render = {t_step * 1e3:.0f} ms"}
+
+
 def lib_hash():
     """Identity of the kernels being timed: the hash of its sources the library carries (mgs_build_id, baked in at compile
     time by csrc/Makefile) -- of the BINARY that runs, not of the working tree."""
@@ -145,19 +189,22 @@ def lib_hash():
     return _lib.build_id()
 
 
-COUNTER_FILES = ("r03_sq_counters.json", "r02_sq_counters.json")
+def counter_files(cfg_name, views):
+    """Committed counter passes for this workload (scripts/gpu_round4.sh writes them), newest round first."""
+    suffix = "" if (cfg_name == "c3" and views == 1) else f"_{cfg_name}" + (f"_v{views}" if views > 1 else "")
+    return [f"r{r:02d}_sq_counters{suffix}.json" for r in (4, 3, 2)]
 
 
-def committed_counters(kernel_substr, build_id):
-    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r03_sq_counters.json, written by
+def committed_counters(kernel_substr, build_id, files):
+    """Per-launch counters of a kernel from the committed rocprofv3 passes (profiles/r04_sq_counters*.json, written by
     scripts/sq_counters.py from runs of THIS command) -- only if they were collected from the binary being timed."""
     why = "no committed counters"
-    for name in COUNTER_FILES:
+    for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)
         except (OSError, ValueError) as e:
-            why = f"{name}: {e}"
+            why = f"{name}: {type(e).__name__}"
             continue
         have = j.get("lib_build_id") or j.get("lib_sha256_16")
         if have != build_id:
@@ -170,6 +217,40 @@ def committed_counters(kernel_substr, build_id):
     return None, why
 
 
+# kernel (stage-timer name, substring of the kernel's symbol, label)
+KERNELS = [("preprocess_fwd", "preprocess_fwd_kernel", "K2 forward preprocess"),
+           ("bin_scatter", "bin_scatter_kernel", "K4' bin scatter"),
+           ("bin_segsort", "bin_segsort_kernel", "K5' segment sort"),
+           ("bin_merge", "bin_merge_emit_kernel", "K6' rank merge + emit"),
+           ("render_fwd", "coop_fwd_pairs_kernel", "K7 render forward"),
+           ("render_bwd", "gm_bwd_kernel", "K8 render backward"),
+           ("preprocess_bwd", "preprocess_bwd_kernel", "K9+K10 backward preprocess")]
+
+
+def model_bytes(P, V, M, F, npix, T, R, nvis, inc, chunks, nblk):
+    """HBM bytes ONE launch of each kernel has to move in THIS dataflow, every array once: P Gaussians, V views
+    per launch (Pv = V P virtual Gaussians), nvis = sum over the views of Gaussians with radii > 0, R = (Gaussian, tile)
+    instances, inc = (8x8 block, Gaussian) incidences the forward's fills kept, chunks = their 64-survivor chunks (the unit
+    of the forward -> backward state: 3 + F partial sums, T_end, T_mid, last_pos per pixel), npix pixels, T tiles, nblk =
+    preprocess workgroups.  Nothing is charged per (pixel, Gaussian) pair or per instance for the gradient sums: they are
+    reduced in registers / LDS and leave as one atomic row per (block, Gaussian), which the L2 merges -- one write-back per
+    visible Gaussian.  These are lower bounds of what the kernel must move, so bytes / time <= the HBM roof."""
+    Pv = V * P
+    rec = 32 + 12 + 4 * F                      # packed record + rgb + feature row of one visible Gaussian
+    state = chunks * 64 * 4 * (3 + F + 3)      # per chunk: partial sums, T_end, T_mid, last_pos
+    ncol = Pv if M else P                      # dL_dcolors rows: per (view, Gaussian) with SH colours
+    zero = 4 * (8 * Pv + 3 * ncol + F * P)     # the backward's accumulator block, zeroed by the forward preprocess
+    return {
+        "preprocess_fwd": Pv * 12 + nvis * (28 + 4 + 12 * M) + Pv * 16 + nvis * (4 + 32 + 12 + 24 + 1) + zero,
+        "bin_scatter": Pv * 12 + nblk * T * 4 + R * 8,
+        "bin_segsort": R * 8 + R * 8,
+        "bin_merge": R * 8 + R * 4,
+        "render_fwd": R * 4 + nvis * rec + inc * 4 + state + npix * (4 * (3 + F) + 8),
+        "render_bwd": inc * 4 + nvis * rec + state + npix * (4 * (3 + F) + 8) + nvis * (32 + 12 + 4 * F),
+        "preprocess_bwd": Pv * 4 + nvis * (12 + 28 + 12 * M + 24 + 1 + 32 + 12) + Pv * 12 + P * (4 + 12 + 24 + 12 * M + 12 + 16),
+    }
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -177,6 +258,7 @@ def main():
         self_launch(args)
     import torch
     import torch.distributed as dist
+    import manigaussian_amd
     from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, check_status
     from manigaussian_amd import synthetic as syn
     from manigaussian_amd.parallel import all_reduce_grads, flat_alias, sparse_all_reduce_grads
@@ -203,6 +285,11 @@ def main():
     n_gpus = world
     if args.tight_bins is not None:
         _lib.set_option("tight_bins", args.tight_bins)
+    if args.fast_exp is not None:
+        _lib.set_option("fast_exp", args.fast_exp)
+    # The package default ("safe") never sizes a workspace speculatively; a training loop that wants a step without any
+    # host-device synchronisation -- and HIP-graph capture -- opts into "async", as this benchmark does (--forward-mode).
+    manigaussian_amd.set_forward_mode(args.forward_mode)
 
     cfg = dict(CONFIGS[args.config])
     for k in ("P", "F", "size", "views", "timesteps"):
@@ -213,19 +300,18 @@ def main():
     M = 4
     sc = syn.make_scene(P, F=F, M=M, seed=0)  # identical on every rank: the replicated Gaussian set
     params = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
-    my_items = []  # dynamic configs: this rank's share of the step's (timestep, view) items
+    plan = None
     if deform:
-        # STRONG scaling: the step's work -- T timesteps x V views -- is fixed; rank r takes a contiguous share of the items,
-        # so that the views of one timestep stay together (one MLP evaluation + one batched render per timestep and rank)
+        # STRONG scaling: the step's work -- T timesteps x V views -- is fixed and shared (parallel.DynamicPlan): ranks that
+        # share a timestep split its MLP by point and its views round-robin
+        from manigaussian_amd.parallel import DynamicPlan, GradBucket, sharded_deformation
         T_total, V_total = max(1, cfg.get("timesteps", 1)), V
-        items = [(t, v) for t in range(T_total) for v in range(V_total)]
-        if len(items) % n_gpus:
-            raise SystemExit(f"bench.py --config {args.config}: {len(items)} (timestep, view) items do not divide over "
-                             f"{n_gpus} ranks")
-        per = len(items) // n_gpus
-        my_items = items[rank * per:(rank + 1) * per]
+        try:
+            plan = DynamicPlan(T_total, V_total, rank, world)
+        except ValueError as e:
+            raise SystemExit(f"bench.py --config {args.config} --gpus {n_gpus}: {e}")
         cams = syn.circle_cameras(max(V_total, 8), W, H, negative_focal=True)
-        renders_total = len(items)
+        renders_total = T_total * V_total
     else:
         cams = syn.circle_cameras(max(n_gpus * V * NR, 8), W, H, negative_focal=True)
         my_cams = [cams[(rank * V * NR + i) % len(cams)] for i in range(V * NR)]
@@ -246,32 +332,35 @@ def main():
     else:
         from manigaussian_amd import GaussianRasterizerBatch
         from manigaussian_amd.deform import DeformationField, tune_gemms
-        from manigaussian_amd.parallel import GradBucket
         if not os.environ.get("MGS_NO_GEMM_TUNING"):
             tune_gemms()  # TunableOp: the warm-up steps time hipBLASLt / rocBLAS candidates per GEMM shape (fp32 either way)
         g = torch.Generator().manual_seed(3)
-        point_latent = torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
-        z_feature = torch.randn(P, 39, generator=g).to(dev)
+        lo, hi = plan.point_rows(P)
+        # point_latent is an activation of the voxel encoder, a LOCAL leaf: this rank holds (and gets the complete gradient
+        # of) the rows of the points it evaluates -- all of them when it works alone on its timesteps
+        point_latent = torch.randn(P, 128, generator=g)[lo:hi].to(dev).requires_grad_(True)
+        z_feature = torch.randn(P, 39, generator=g)[lo:hi].to(dev)
         field = DeformationField().to(dev)
         with torch.no_grad():  # the reference zero-initialises fc_1; give the deltas some life without exploding the scene
             for p_ in field.parameters():
                 p_.mul_(0.05)
-        # the MLP's parameter gradients live in ONE flat buffer (the only thing a trainer reduces: point_latent is an
-        # activation of the voxel encoder, a local leaf here); autograd accumulates into it in place over the timesteps
-        # (two of them alternate when N > 1, so that one step's asynchronous all-reduce may overlap the next step)
+        # the MLP's parameter gradients live in ONE flat buffer (the only thing a trainer all-reduces); autograd accumulates
+        # into it in place over the timesteps (two alternate when N > 1: a step's asynchronous all-reduce may overlap the next)
         buckets = [GradBucket(dict(field.named_parameters())) for _ in range(2 if world > 1 else 1)]
         bucket_turn = [0]
         plist = list(field.parameters())
         all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in cams]
         groups = []  # (timestep, batched rasterizer over this rank's views of it, action, targets)
-        for t in sorted({t for t, _ in my_items}):
-            vs = [v for tt, v in my_items if tt == t]
+        for t in plan.timesteps:
+            vs = plan.views
             gt = torch.Generator().manual_seed(100 + t)
             groups.append(dict(t=t, views=vs, rast=GaussianRasterizerBatch([all_settings[v] for v in vs]),
                                action=torch.randn(1, 8, generator=gt).to(dev),
                                tgt_c=torch.rand(V_total, 3, H, W, generator=gt)[vs].to(dev),
                                tgt_f=torch.randn(V_total, F, H, W, generator=gt)[vs].to(dev)))
         n_c, n_f = float(renders_total * 3 * H * W), float(renders_total * F * H * W)  # the loss is a mean over ALL renders
+        if plan.group_size > 1 and args.mode == "graph":
+            args.mode = "eager-st"  # collectives inside the step (all-gather / reduce-scatter): the step is enqueued eagerly
 
     last_radii = [None]
 
@@ -284,6 +373,15 @@ def main():
                         language_feature_precomp=params["language_feature"], scales=params["scales"],
                         rotations=params["rotations"])
 
+    def deform_group(gr):
+        """One timestep on this rank up to the rendered images: (point-sharded) MLP -> apply -> one batched render."""
+        nxt = sharded_deformation(field, point_latent, z_feature, params["means3D"].detach(), params["shs"].detach(),
+                                  params["rotations"].detach(), params["scales"].detach(), params["opacities"].detach(),
+                                  action=gr["action"], group=plan.group)
+        return gr["rast"](nxt["xyz"], None, nxt["opacity"], shs=nxt["sh"],
+                          language_feature_precomp=params["language_feature"].detach(), scales=nxt["scale"],
+                          rotations=nxt["rot"])
+
     def compute_step():
         """forward + backward of this rank's render(s); returns the gradients (views of ONE allocation per render)."""
         if deform:
@@ -292,12 +390,8 @@ def main():
             bucket.attach()       # zero the flat MLP-gradient buffer, point every .grad at its view
             point_latent.grad = None
             for gr in groups:     # one timestep: MLP -> apply -> one batched render of this rank's views -> backward
-                nxt = field(point_latent, z_feature, params["means3D"].detach(), params["shs"].detach(),
-                            params["rotations"].detach(), params["scales"].detach(), params["opacities"].detach(),
-                            action=gr["action"])
-                color, feat, _ = gr["rast"](nxt["xyz"], None, nxt["opacity"], shs=nxt["sh"],
-                                            language_feature_precomp=params["language_feature"].detach(),
-                                            scales=nxt["scale"], rotations=nxt["rot"])
+                color, feat, radii = deform_group(gr)
+                last_radii[0] = radii
                 loss = ((color - gr["tgt_c"]) ** 2).sum() / n_c + 0.01 * ((feat - gr["tgt_f"]) ** 2).sum() / n_f
                 loss.backward()
             return [bucket.flat]
@@ -405,6 +499,8 @@ def main():
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
+            if args.backend == "gloo":
+                t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -436,7 +532,8 @@ def main():
         for _ in range(3):
             _lib.check(_lib.lib().mgs_calibration_kernel(1000, sink.data_ptr(), None), "calibration")
         torch.cuda.synchronize()
-    modes = [args.mode] if args.only_mode else [args.mode] + [m for m in ("graph", "eager", "eager-st") if m != args.mode]
+    all_modes = ("graph", "eager", "eager-st") if not (deform and plan.group_size > 1) else ("eager", "eager-st")
+    modes = [args.mode] if args.only_mode else [args.mode] + [m for m in all_modes if m != args.mode]
     results, errors, long_runs = {}, {}, {}
     headline_stepper = None
     for m in modes:
@@ -450,17 +547,6 @@ def main():
             if m == args.mode and m != "graph":
                 raise
             errors[m] = f"{type(e).__name__}: {e}"[:300]
-    # the dominant kernel timed live: hipEvents around the render backward on its launch stream (eager steps: events
-    # cannot be read back from inside a captured graph)
-    torch.autograd.set_multithreading_enabled(False)
-    _lib.profile_read(reset=True)
-    _lib.set_option("profile", 1)
-    e1 = Eager()
-    run(e1, min(max(args.steps, 20), 200), collective=False)
-    sync_all()
-    _lib.set_option("profile", 0)
-    prof = _lib.profile_read(reset=True)
-    torch.autograd.set_multithreading_enabled(True)
     mode = args.mode if args.mode in results else next(iter(results))
     elapsed, steps = results[mode]
 
@@ -475,33 +561,73 @@ def main():
         without_ms = (lr0[0] / lr0[1]) if lr0 else el0 / k0
         exposed_ms = max(0.0, with_ms - without_ms) * 1e3
 
-    # stage breakdown, untimed extra pass (eager: the stage timers are host-side event records)
+    # every kernel timed live: hipEvents around each launch on its launch stream (eager steps: events cannot be read back
+    # from inside a captured graph), an untimed extra pass
+    torch.autograd.set_multithreading_enabled(False)
+    _lib.profile_read(reset=True)
     _lib.set_option("profile", 2)
     e = Eager()
-    run(e, min(steps, 20), collective=False)
+    n_prof = min(max(args.steps, 20), 100) if not deform else min(max(args.steps, 4), 10)
+    run(e, n_prof, collective=False)
     sync_all()
     _lib.set_option("profile", 0)
-    stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.profile_read(reset=True).items()}
+    prof = _lib.profile_read(reset=True)
+    torch.autograd.set_multithreading_enabled(True)
+    stages = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items()}
 
-    # measured instance count (R) of what ONE launch of the render kernels covers on this rank
-    from manigaussian_amd import _C
-    launches_per_step = NR
-    with torch.no_grad():
-        et = torch.empty(0, device=dev)
+    # what ONE launch of the render kernels covers on this rank: instances (R), visible Gaussians, (block, Gaussian)
+    # incidences and chunks of the forward -> backward state (mgs_forward_stats, a blocking diagnostic)
+    import ctypes
+    launches_per_step = len(groups) if deform else NR
+    launch_views = len(groups[0]["views"]) if deform else V
+    torch.cuda.synchronize()
+    # (a forward of its own whose outputs stay alive: the autograd node keeps the workspaces the statistics are read from)
+    color_s, feat_s, radii_s = deform_group(groups[0]) if deform else render_once(0)
+    torch.cuda.synchronize()
+    handle = color_s.grad_fn.num_rendered  # the forward's ForwardHandle (manigaussian_amd/_C.py)
+    R = int(handle)
+    nvis = int((radii_s > 0).sum().item())
+    inc_, ch_ = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().mgs_forward_stats(ctypes.byref(handle.a), launch_views if (deform or V > 1) else 0,
+                                            ctypes.byref(inc_), ctypes.byref(ch_), None), "mgs_forward_stats")
+    incidences, chunks = int(inc_.value), int(ch_.value)
+    del color_s, feat_s, radii_s, handle
 
-        def count(xyz, rot, st):
-            return _C.rasterize_gaussians(st.bg, xyz, et, params["language_feature"], params["opacities"], params["scales"],
-                                          rot, 1.0, et, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, H, W,
-                                          params["shs"], 1, st.campos, False, False, True)[0]
-        if deform:  # the first timestep's batch of views stands for a launch
-            gr = groups[0]
-            nxt = field(point_latent, z_feature, params["means3D"], params["shs"], params["rotations"], params["scales"],
-                        params["opacities"], action=gr["action"])
-            R = sum(count(nxt["xyz"], nxt["rot"], all_settings[v]) for v in gr["views"])
-            launch_views, launches_per_step = len(gr["views"]), len(groups)
-        else:
-            R = sum(count(params["means3D"], params["rotations"], st) for st in all_settings[:V])
-            launch_views = V
+    # the deformation MLP apart from the rasterizer: forward + backward of this rank's points, hipEvent-timed
+    mlp_block = None
+    if deform:
+        from manigaussian_amd.deform import assemble_deform_input
+        n_loc = int(point_latent.shape[0])
+        gr = groups[0]
+        lo, hi = plan.point_rows(P)
+
+        def mlp_only():
+            zx = assemble_deform_input(point_latent, z_feature, params["means3D"].detach()[lo:hi], params["shs"].detach()[lo:hi],
+                                       params["rotations"].detach()[lo:hi], params["scales"].detach()[lo:hi],
+                                       params["opacities"].detach()[lo:hi], None, gr["action"])
+            delta, _ = field.mlp(zx)
+            delta.backward(torch.ones_like(delta))
+        for _ in range(2):
+            mlp_only()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_it = 5
+        ev0.record()
+        for _ in range(n_it):
+            mlp_only()
+        ev1.record()
+        torch.cuda.synchronize()
+        mlp_ms = ev0.elapsed_time(ev1) / n_it
+        point_latent.grad = None
+        macs = 70 * 512 + 3 * 128 * 512 + 10 * 512 * 512 + 512 * 7  # per point: lin_in, 3 lin_z, 5 blocks x 2, lin_out
+        flops = 3 * 2 * macs * n_loc                                  # forward + data gradients + weight gradients
+        mlp_block = {"bound": "mfma", "dtype": "f32", "achieved": flops / (mlp_ms * 1e-3) / 1e12,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / (mlp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_timestep_per_rank": flops,
+                     "ms_per_timestep_per_rank": mlp_ms, "points_per_rank": n_loc,
+                     "what": "input assembly + ResnetFC forward + backward (fp32 GEMMs on hipBLASLt / rocBLAS through torch, "
+                             "fused HIP elementwise passes) of this rank's points for one timestep, hipEvent-timed apart from "
+                             "the rasterizer; FLOPs = 3 x 2 x 3.28 M MACs per point (the elementwise passes add time, no FLOPs)"}
+
     dev_ids = [None] * world
     if world > 1:
         dist.all_gather_object(dev_ids, torch.cuda.current_device())
@@ -510,37 +636,51 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / steps * 1e3
-        renders = renders_total // n_gpus            # renders per GPU per step
+        renders = launches_per_step * launch_views   # renders per GPU per step
         value = P * renders_total * steps / elapsed  # whole job: every render of every rank
-        bwd_ms, bwd_n = prof["render_bwd"]
-        bwd_avg_ms = bwd_ms / max(bwd_n, 1)
         npix = W * H * launch_views  # pixels one launch covers
-        bytes_k8 = R * (112 + 12 * F) + npix * (20 + 4 * F)
-        achieved = bytes_k8 / (bwd_avg_ms * 1e-3) / 1e9 if bwd_avg_ms > 0 else 0.0
-        bytes_path = (launch_views * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)) * launches_per_step
+        T_tiles = ((W + 15) // 16) * ((H + 15) // 16) * launch_views
+        nblk = launch_views * ((P + 1023) // 1024)
+        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, chunks, nblk)
         so_hash = lib_hash()
-        def roof_block(label, substr, avg_ms, launches, bytes_alg):
-            """What bounds a kernel, from the committed counter passes of THIS binary (profiles/r03_sq_counters.json): no
-            throughput roof is near -- the waves spend their cycles waiting on dependent instructions and on memory / LDS /
-            barriers (SQ_WAIT_*).  The HBM line (algorithmic and counter bytes) is kept beside the issue numbers."""
-            cnt, why = committed_counters(substr, so_hash)
+        cfiles = counter_files(args.config, launch_views if not deform else 1) if not deform else \
+            [f"r04_sq_counters_{args.config}.json"]
+        violations = []
+
+        def hbm_line(stage, substr, label):
+            """The HBM line of one kernel: model bytes per launch / its average launch duration (hipEvents on the launch
+            stream) against 8 TB/s; `traffic` = HBM bytes per launch by the counters (2 * FETCH_SIZE + WRITE_SIZE KiB, the
+            guide's gfx950 correction) from the committed passes of THIS binary, and the fraction they give."""
+            avg_ms, (tot_ms, launches) = stages.get(stage, 0.0), prof.get(stage, (0.0, 0))
+            cnt, why = committed_counters(substr, so_hash, cfiles)
             traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
-            ach = bytes_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            cycles = avg_ms * 1e-3 * 2.4e9  # upper bound: 2.4 GHz peak clock
-            # the contract's block: the HBM line of this kernel -- ALGORITHMIC bytes per launch (SURVEY.md 8d) over the launch
-            # duration measured live with hipEvents on the launch stream, against 8 TB/s; `traffic` = HBM bytes per launch by
-            # the counters (2 * FETCH_SIZE + WRITE_SIZE KiB, the guide's gfx950 correction) from the committed passes
+            ach = mb[stage] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             rb = {"kernel": label, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
-                  "algorithmic_bytes_per_launch": bytes_alg,
+                  "algorithmic_bytes_per_launch": mb[stage],
                   "frac_by_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
-                  "counters_note": why, "lib_build_id": so_hash}
-            if cnt and cnt.get("SQ_INSTS_VALU") and cycles > 0:
-                # beside it, what the counters say actually limits the kernel: no throughput roof is near, the waves wait
-                gips = cnt["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
-                wc = cnt.get("SQ_WAVE_CYCLES") or 0.0
-                rb["limiter"] = {
-                    "summary": "latency (dependent issue + waits): HBM, VALU issue and the matrix pipe are all far from peak",
+                  "traffic_over_algorithmic": (traffic / mb[stage]) if traffic and mb[stage] else None,
+                  "counters_note": why}
+            for k in ("frac", "frac_by_counter_bytes"):
+                if rb[k] is not None and rb[k] > 1.0:
+                    violations.append(f"{label}: {k} = {rb[k]:.3f}")
+            return rb, cnt
+
+        by_kernel = {}
+        cnts = {}
+        for stage, substr, label in KERNELS:
+            by_kernel[stage], cnts[stage] = hbm_line(stage, substr, label)
+
+        def limiter(stage):
+            """What the counters say limits a render kernel: no throughput roof is near -- the waves spend their cycles
+            waiting on dependent instructions and on memory / LDS / barriers (SQ_WAIT_*)."""
+            cnt, avg_ms = cnts[stage], stages.get(stage, 0.0)
+            if not (cnt and cnt.get("SQ_INSTS_VALU") and avg_ms > 0):
+                return None
+            cycles = avg_ms * 1e-3 * 2.4e9  # upper bound: 2.4 GHz peak clock
+            gips = cnt["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
+            wc = cnt.get("SQ_WAVE_CYCLES") or 0.0
+            return {"summary": "latency (dependent issue + waits): HBM, VALU issue and the matrix pipe are all far from peak",
                     "valu_issue": {"achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": gips / VALU_PEAK_GIPS},
                     "valu_busy_frac_of_simd_cycles": (cnt.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / (1024 * cycles),
                     "mfma_busy_frac_of_simd_cycles": cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cycles),
@@ -549,18 +689,36 @@ def main():
                     "per_launch": {k: cnt.get(k) for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA",
                                                            "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD",
                                                            "SQ_INSTS_VMEM_WR")}}
-            return rb
 
-        roof = roof_block("K8 render backward (gm_bwd_kernel)", "gm_bwd_kernel", bwd_avg_ms, bwd_n, bytes_k8)
-        bytes_k7 = R * (40 + 4 * F) + npix * (4 * (3 + F) + 8)
-        roof_fwd = roof_block("K7 render forward (coop_fwd_pairs_kernel)", "coop_fwd_pairs_kernel",
-                              stages.get("render_fwd", 0.0), min(steps, 20), bytes_k7)
+        roof = dict(by_kernel["render_bwd"], kernel="K8 render backward (gm_bwd_kernel)", lib_build_id=so_hash)
+        roof["limiter"] = limiter("render_bwd")
+        bwd_ms = stages.get("render_bwd", 0.0)
+        s8d = R * (112 + 12 * F) + npix * (20 + 4 * F)
+        roof["survey_8d_charge"] = {
+            "bytes_per_launch": s8d, "frac_if_charged": (s8d / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if bwd_ms > 0 else None,
+            "note": "SURVEY.md 8d's K8 rows R(112+12F) + N(20+4F) charge the reference's per-INSTANCE read-modify-write "
+                    "atomics, which this kernel never issues (register / LDS reduction, one atomic row per (block, Gaussian)): "
+                    "not a bound of this dataflow -- it exceeds 1 at large R / P -- and kept only so that earlier rounds' "
+                    "numbers stay comparable"}
+        roof_fwd = dict(by_kernel["render_fwd"], kernel="K7 render forward (coop_fwd_pairs_kernel)")
+        roof_fwd["limiter"] = limiter("render_fwd")
+        path_model = sum(mb.values()) * launches_per_step
+        path_traffic = None
+        if all(by_kernel[k]["traffic"] for k in by_kernel):
+            path_traffic = sum(by_kernel[k]["traffic"] for k in by_kernel) * launches_per_step
+        s8d_path = (launch_views * P * (434 + 48 * M + 4 * F) + R * (196 + 16 * F) + npix * (40 + 8 * F)) * launches_per_step
+        rast_ms = sum(stages.get(k, 0.0) for k, _, _ in KERNELS) * launches_per_step  # the rasterizer's kernels per step
+        path_frac = path_model / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rast_ms > 0 else None
+        if path_frac is not None and path_frac > 1.0:
+            violations.append(f"path_hbm: frac = {path_frac:.3f}")
+        if mlp_block is not None and mlp_block["frac"] > 1.0:
+            violations.append(f"roofline_mlp: frac = {mlp_block['frac']:.3f}")
         out = {
             "metric": "Gaussians rasterized/sec (fwd+bwd), 128x128, 32 feat-ch; HBM GB/s vs peak",
             "value": value, "unit": "Gaussians/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "extra_warmup_steps": extra_warmup.get(mode, 0),
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if deform else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "mode": mode,
+            "dtype": "f32", "data": "synthetic", "mode": mode, "forward_mode": manigaussian_amd.forward_mode(),
             "long_run": ({"steps": long_runs[mode][1], "ms_per_step": long_runs[mode][0] / long_runs[mode][1] * 1e3,
                           "value": P * renders_total * long_runs[mode][1] / long_runs[mode][0],
                           "why": f"the {steps}-step region lasted under {MIN_TIMED_MS:.0f} ms; the same stepper over a longer "
@@ -573,14 +731,20 @@ def main():
                        "views_per_gpu": (renders if deform else V), "timesteps_per_step": cfg.get("timesteps", 1) if deform else 1,
                        "renders_per_step_per_gpu": renders, "renders_per_step_total": renders_total,
                        "render_launch_views": launch_views, "num_rendered_R": int(R), "R_over_P": R / (P * launch_views),
-                       "tight_bins": _lib.get_option("tight_bins"),
+                       "visible_gaussians_per_launch": nvis, "block_gaussian_incidences_per_launch": incidences,
+                       "chunks_per_launch": chunks,
+                       "tight_bins": _lib.get_option("tight_bins"), "fast_exp": _lib.get_option("fast_exp"),
                        "deformation": ("DeformationField per timestep: HIP input assembly -> fp32 MLP 70->512x5->7 (torch GEMMs, "
                                        "fused HIP elementwise passes) -> HIP apply; gradients of the MLP parameters (one flat "
                                        "bucket) and of point_latent") if deform else None,
-                       "strong_scaling_recipe": (f"python bench.py --config {args.config} --gpus N for N in "
-                                                 f"{[n for n in (1, 2, 4, 8, 16) if renders_total % n == 0]}: the step's "
-                                                 f"{renders_total} renders are shared, {renders_total}/N per GPU") if deform else None,
+                       "partition": (dict(plan.describe(P), timesteps_total=plan.n_timesteps, views_total=plan.n_views,
+                                          allreduce_bytes_per_step=ar_bytes) if deform else None),
+                       "strong_scaling_recipe": (f"python bench.py --config {args.config} --gpus N: the step's "
+                                                 f"{renders_total} renders are shared; ranks that share a timestep split its "
+                                                 f"MLP by point (P/N points each at N > timesteps)") if deform else None,
                        "collective": ("none" if n_gpus == 1 else
+                                      ("per timestep an all-gather of the [P,7] deltas and a reduce-scatter of dL/d delta "
+                                       "inside the ranks that share it; " if plan.group_size > 1 else "") +
                                       "1 asynchronous all-reduce of the flat MLP-gradient bucket per step (point_latent is a "
                                       "local leaf)" if deform else
                                       "1 in-place all-reduce of the per-Gaussian parameter gradients per step, overlapping the "
@@ -590,23 +754,39 @@ def main():
                             "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_ids": dev_ids,
                             "allreduce_bytes_per_step": ar_bytes,
                             "allreduce_exposed_ms_per_step": exposed_ms},
-            "roofline": roof, "roofline_fwd": roof_fwd,
-            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": bytes_path,
-                         "achieved_GBps": bytes_path * n_gpus / (ms_step * 1e-3) / 1e9,
-                         "frac_of_peak": bytes_path / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "rasterizer path only (SURVEY.md 8d); the deformation MLP's GEMMs are MFMA work, not in it"
-                                 if deform else "SURVEY.md 8d, whole rasterizer path"},
+            "roofline": roof, "roofline_fwd": roof_fwd, "roofline_by_kernel": by_kernel,
+            "roofline_mlp": mlp_block,
+            "path_hbm": {"algorithmic_bytes_per_step_per_gpu": path_model,
+                         "kernel_ms_per_step_per_gpu": rast_ms,
+                         "achieved_GBps": (path_model / (rast_ms * 1e-3) / 1e9) if rast_ms > 0 else None,
+                         "frac_of_peak": path_frac,
+                         "counter_bytes_per_step_per_gpu": path_traffic,
+                         "frac_of_peak_by_counter_bytes": (path_traffic / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if path_traffic and rast_ms > 0 else None,
+                         "survey_8d_bytes_per_step_per_gpu": s8d_path,
+                         "note": "the rasterizer's seven kernels: model bytes (every array once, DESIGN.md 4) over the sum of "
+                                 "their launch durations; SURVEY.md 8d's figure (per-instance atomics charged) beside it"
+                                 + ("; the deformation MLP's GEMMs are MFMA work: roofline_mlp" if deform else "")},
+            "roofline_check": {"all_fractions_le_1": not violations, "violations": violations or None},
             "stages_ms": stages,
         }
-        if not args.no_cpu_baseline and n_gpus == 1 and not deform:
-            out["cpu_baseline"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
+        if not args.no_cpu_baseline and n_gpus == 1:
+            if deform:
+                out["cpu_baseline"] = cpu_baseline_dynamic(syn, sc, cam, d_color_h, d_feat_h, P, cfg.get("timesteps", 1),
+                                                           renders_total, args.cpu_seconds * 2)
+            else:
+                out["cpu_baseline"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        if violations:
+            print("bench.py: roofline fraction above 1: " + "; ".join(violations), file=sys.stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if args.strict_roofline and rank == 0 and violations:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -259,14 +259,16 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         T = ((W + 15) // 16) * ((H + 15) // 16)
         guess = st.guess(key)
         cap_worst = P * T  # every Gaussian in every tile
-        if cap_worst < (1 << 30) and L.mgs_binning_bytes2(cap_worst, 0, W, H, F) <= _state.safe_bytes():
-            guess = (cap_worst, L.mgs_chunk_pool_max(cap_worst, W, H))  # cannot overflow: no marks, no warm-up call needed
+        cannot_overflow = cap_worst < (1 << 30) and L.mgs_binning_bytes2(cap_worst, 0, W, H, F) <= _state.safe_bytes()
+        if cannot_overflow:
+            guess = (cap_worst, L.mgs_chunk_pool_max(cap_worst, W, H))  # no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and
-                _state.forward_mode() == "async" and opts["bin_mode"] == 1 and T <= 4096)
+                _state.lazy_allowed(cannot_overflow) and opts["bin_mode"] == 1 and T <= 4096)
         if capturing and not lazy:
-            raise RuntimeError("capturing a rasterizer forward into a HIP graph needs the asynchronous path: run this shape "
-                               "eagerly (twice) first so that its workspace sizes are known, with debug=False")
+            raise RuntimeError("capturing a rasterizer forward into a HIP graph needs the asynchronous path: "
+                               "manigaussian_amd.set_forward_mode('async'), then run this shape eagerly (twice) first so that "
+                               "its workspace sizes are known, with debug=False")
         if lazy:
             cap, pool = guess
         else:  # blocking path: the chunk pool is the worst case for the capacity (cannot overflow)

@@ -1,9 +1,20 @@
 """Host-side bookkeeping of the asynchronous forward (include/mgsplat.h: mgs_rasterize_forward with async_forward = 1).
 
 The reference blocks every forward on a cudaMemcpy of `num_rendered` (RAST/cuda_rasterizer/rasterizer_impl.cu:284) because
-its binning buffer is sized from that count.  Here a forward sizes its workspace from what earlier forwards of the same
-shape needed (high-water marks + head-room), enqueues everything and returns; the device reports {instances, chunk records
-used, overflow} through two pinned host words.  This module owns
+its binning buffer is sized from that count.  Three forward modes (set_forward_mode / MGS_FORWARD_MODE):
+
+  "safe" (default)  a forward can NEVER hand back incomplete images.  A shape whose worst-case workspace fits the budget
+                    (set_safe_workspace, default 1 GB: ManiGaussian's own 16 384-Gaussian shape needs 206 MB) is enqueued
+                    without any host-device synchronisation -- it cannot overflow; every other shape waits for the instance
+                    count like the reference does and sizes its buffer from it (a retry when the scene grew).
+  "async" (opt-in)  every shape is enqueued without synchronisation: the workspace is sized from what earlier forwards of the
+                    same shape needed (high-water marks + head-room) and the device reports {instances, chunk records used,
+                    overflow} through two pinned host words.  What HIP-graph capture and a GPU-bound 0.15 ms step need;
+                    the price is the overflow protocol below (a scene that outgrows its marks is repaired at backward entry
+                    with a RuntimeWarning, or raises late).
+  "blocking"        every forward waits for the count (the reference's behaviour, also for small shapes).
+
+This module owns
 
   * the ring of pinned status slots (one per in-flight forward, tagged so that a stale write is recognisable),
   * the high-water marks per (device, problem shape),
@@ -26,23 +37,33 @@ from . import _lib
 
 NSLOTS = 1024  # status slots per device (two 64-bit words each); far more than forwards can be in flight
 
-_MODE = os.environ.get("MGS_FORWARD_MODE", "async")  # "async" | "blocking"
+_MODE = os.environ.get("MGS_FORWARD_MODE", "safe")  # "safe" | "async" | "blocking"
 _STATES = {}
 _LOCK = threading.Lock()
 _TAG = [0]
 
 
 def set_forward_mode(mode: str):
-    """"async" (default): steady-state forwards return without any host-device synchronisation; "blocking": every
-    forward waits for the instance count like the reference does."""
+    """"safe" (default): no host-device synchronisation for shapes whose worst-case workspace fits the budget (they cannot
+    overflow), the reference's blocking read of the instance count for every other shape -- a forward never returns
+    incomplete images; "async": no synchronisation for any shape, workspaces sized from earlier calls (opt-in: see the
+    module docstring for what an overflow then means); "blocking": every forward waits like the reference does.
+    Returns the previous mode."""
     global _MODE
-    if mode not in ("async", "blocking"):
-        raise ValueError("forward mode is 'async' or 'blocking'")
-    _MODE = mode
+    if mode not in ("safe", "async", "blocking"):
+        raise ValueError("forward mode is 'safe', 'async' or 'blocking'")
+    old, _MODE = _MODE, mode
+    return old
 
 
 def forward_mode() -> str:
     return _MODE
+
+
+def lazy_allowed(cannot_overflow: bool) -> bool:
+    """May a forward be enqueued without waiting for its instance count?  "async": always (marks permitting); "safe": only
+    with a workspace that cannot overflow; "blocking": never."""
+    return _MODE == "async" or (_MODE == "safe" and cannot_overflow)
 
 
 # Head-room of an asynchronous forward's workspace over the high-water marks of its shape: the scene may grow by these
@@ -215,11 +236,11 @@ class DeviceState:
                     self.deferred.append(p)
                 warnings.warn(msg + "; the call's backward re-renders on the blocking path before it runs, but a loss computed "
                               "from those images was computed from incomplete images.  For scenes that grow abruptly use "
-                              "manigaussian_amd.set_forward_mode('blocking') or a larger set_headroom().", RuntimeWarning,
+                              "manigaussian_amd.set_forward_mode('safe') (the default) or a larger set_headroom().", RuntimeWarning,
                               stacklevel=4)
                 return None
             return (msg + " and its gradients were computed on the incomplete state; re-run the step, or use "
-                    "manigaussian_amd.set_forward_mode('blocking') for scenes that grow abruptly.")
+                    "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.")
         return f"rasterizer forward failed: {_lib.last_error()} (code {rc})"
 
     def check_captured(self):

@@ -81,13 +81,16 @@ class _RasterizeViews(torch.autograd.Function):
             guess = st.guess(key)
             T1 = ((W + 15) // 16) * ((H + 15) // 16)
             cap_worst = V * P * T1  # every Gaussian in every tile of every view
-            if 0 < cap_worst < (1 << 30) and L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes():
-                guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))  # cannot overflow
-            lazy = (guess is not None and _state.forward_mode() == "async" and opts["bin_mode"] == 1
+            cannot_overflow = (0 < cap_worst < (1 << 30) and
+                               L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes())
+            if cannot_overflow:
+                guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))
+            lazy = (guess is not None and _state.lazy_allowed(cannot_overflow) and opts["bin_mode"] == 1
                     and not s0.prefiltered)
             if capturing and not lazy:
-                raise RuntimeError("capturing a batched forward into a HIP graph needs the asynchronous path: run this "
-                                   "shape eagerly (twice) first so that its workspace sizes are known")
+                raise RuntimeError("capturing a batched forward into a HIP graph needs the asynchronous path: "
+                                   "manigaussian_amd.set_forward_mode('async'), then run this shape eagerly (twice) first so "
+                                   "that its workspace sizes are known")
             if lazy:
                 cap, pool = guess
             else:

@@ -199,16 +199,28 @@ import contextlib
 
 @contextlib.contextmanager
 def _marks_only():
-    """Size asynchronous forwards from the high-water marks even for shapes whose worst-case workspace is small enough to be
-    allocated outright (the default for them): the tests of the marks / overflow machinery need it."""
+    """The opt-in asynchronous mode with workspaces sized from the high-water marks even for shapes whose worst-case workspace
+    is small enough to be allocated outright: the tests of the marks / overflow machinery need it."""
     import manigaussian_amd as mg
     from manigaussian_amd import _state
     old = _state.safe_bytes()
     mg.set_safe_workspace(0)
+    old_mode = mg.set_forward_mode("async")
     try:
         yield
     finally:
         _state._SAFE_BYTES = old
+        mg.set_forward_mode(old_mode)
+
+
+@contextlib.contextmanager
+def _forward_mode(mode):
+    import manigaussian_amd as mg
+    old = mg.set_forward_mode(mode)
+    try:
+        yield
+    finally:
+        mg.set_forward_mode(old)
 
 
 def test_capacity_retry_and_two_call_path_match_fused_forward():
@@ -297,12 +309,12 @@ def _impl_test_async_forward_equals_blocking_forward_and_never_synchronises():
     d = {k: v.to(dev) for k, v in sc.items()}
     rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
     dC, dF = dC.to(dev), dF.to(dev)
-    mg.set_forward_mode("blocking")
+    _old_mode = mg.set_forward_mode("blocking")
     try:
         c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
         torch.cuda.synchronize()
     finally:
-        mg.set_forward_mode("async")
+        mg.set_forward_mode(_old_mode)
     st = _state.device_state(dev)
     key = (P, W, W, F, 1)
     for _ in range(3):  # learn both marks (the chunk-record mark arrives with the render's report)
@@ -349,12 +361,12 @@ def _impl_test_async_overflow_is_reported_loudly_and_recovers():
     d = {k: v.to(dev) for k, v in sc.items()}
     rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
     dC, dF = dC.to(dev), dF.to(dev)
-    mg.set_forward_mode("blocking")
+    _old_mode = mg.set_forward_mode("blocking")
     try:
         c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
         torch.cuda.synchronize()
     finally:
-        mg.set_forward_mode("async")
+        mg.set_forward_mode(_old_mode)
     for _ in range(3):
         _train_step(d, rast, dC, dF)
         mg.check_status(dev)
@@ -422,12 +434,12 @@ def test_async_overflow_of_a_view_batch_is_repaired_at_backward_entry():
             gs = torch.autograd.grad([c, f], list(d.values()), [dCd, dFd])
             return c, f, r, gs
 
-        mg.set_forward_mode("blocking")
+        _old_mode = mg.set_forward_mode("blocking")
         try:
             c0, f0, r0, g0 = step()
             torch.cuda.synchronize()
         finally:
-            mg.set_forward_mode("async")
+            mg.set_forward_mode(_old_mode)
         for _ in range(3):
             step()
             mg.check_status(dev)
@@ -504,15 +516,74 @@ def test_small_shapes_get_their_worst_case_workspace_and_cannot_overflow():
         mg.check_status(dev)  # would raise if the second scene had outgrown a workspace sized from the first
         outs[name] = (c, f, r)
     with _marks_only():  # the same two scenes through the blocking path (exact sizes)
-        mg.set_forward_mode("blocking")
+        _old_mode = mg.set_forward_mode("blocking")
         try:
             for name, d in (("small", small), ("big", big)):
                 c, f, r = rast(d["means3D"], torch.zeros(P, 3, device=dev), d["opacities"], shs=d["shs"],
                                language_feature_precomp=d["language_feature"], scales=d["scales"], rotations=d["rotations"])
                 assert torch.equal(c, outs[name][0]) and torch.equal(f, outs[name][1]) and torch.equal(r, outs[name][2])
         finally:
-            mg.set_forward_mode("async")
+            mg.set_forward_mode(_old_mode)
     assert int((outs["big"][2] > 0).sum()) > 0
+
+
+def test_default_mode_never_returns_incomplete_images_when_a_scene_grows():
+    """under the DEFAULT options ("safe" forward mode) an abruptly growing scene of a shape whose
+    worst-case workspace does NOT fit the budget (forced here with a 1 MB budget; BASELINE configs[2] needs 4 GB against the
+    default 1 GB) yields the correct images and gradients in the very call that grew, with no warning and nothing to raise
+    later -- the reference's behaviour (RAST/cuda_rasterizer/rasterizer_impl.cu:282-284 sizes the buffer from the count it
+    waited for).  Three scenes of one shape in a row: sparse, 80 x denser, sparse again; single view and a 3-view batch."""
+    import warnings
+    import manigaussian_amd as mg
+    from manigaussian_amd import GaussianRasterizerBatch, _state
+    assert mg.forward_mode() == "safe", "the package default must be the mode that cannot return incomplete images"
+    dev = torch.device("cuda:0")
+    P, F, W = 9001, 32, 128
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    cams = syn.circle_cameras(3, W, W, negative_focal=True)
+    mk = lambda c: GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, bg=(0.1, 0.2, 0.3), device=dev))  # noqa: E731
+    rast, rastV = GaussianRasterizer(mk(cam)), GaussianRasterizerBatch([mk(c) for c in cams])
+    dCd, dFd = dC.to(dev), dF.to(dev)
+    dCv, dFv = torch.stack([dCd] * 3), torch.stack([dFd] * 3)
+    scenes = []
+    for mult in (0.05, 4.0, 0.05):
+        d = {k: v.to(dev) for k, v in sc.items()}
+        d["scales"] = d["scales"] * mult
+        scenes.append(d)
+
+    def step(d, batched):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in d.items()}
+        if batched:
+            c, f, r = rastV(leaves["means3D"], None, leaves["opacities"], shs=leaves["shs"],
+                            language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                            rotations=leaves["rotations"])
+            gs = torch.autograd.grad([c, f], list(leaves.values()), [dCv, dFv])
+        else:
+            c, f, r = rast(leaves["means3D"], torch.zeros(P, 3, device=dev), leaves["opacities"], shs=leaves["shs"],
+                           language_feature_precomp=leaves["language_feature"], scales=leaves["scales"],
+                           rotations=leaves["rotations"])
+            gs = torch.autograd.grad([c, f], list(leaves.values()), [dCd, dFd])
+        return c, f, r, gs
+
+    old_budget = _state.safe_bytes()
+    mg.set_safe_workspace(1)
+    try:
+        for batched in (False, True):
+            with _forward_mode("blocking"):  # the expected values: every scene on the blocking path, on its own
+                want = [step(d, batched) for d in scenes]
+                torch.cuda.synchronize()
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                got = [step(d, batched) for d in scenes]
+                torch.cuda.synchronize()
+                mg.check_status(dev)  # nothing to raise
+            assert not [x for x in w if issubclass(x.category, RuntimeWarning)], [str(x.message) for x in w]
+            for (c1, f1, r1, g1), (c0, f0, r0, g0) in zip(got, want):
+                assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+                for a, b in zip(g1, g0):
+                    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12  # float atomics: order differs
+    finally:
+        _state._SAFE_BYTES = old_budget
 
 
 def test_forward_backward_captured_into_a_hip_graph_replays_bit_identically():
@@ -644,6 +715,45 @@ def test_live_reference(case):
     assert R_hip[0] == R_ref == int(state.num_rendered), (R_hip, R_ref, state.num_rendered)
     assert 0 < R_hip[1] <= R_ref, (R_hip, R_ref)
     util.report(repr(case), num_rendered_reference=R_ref, num_rendered_tight0=R_hip[0], num_rendered_tight1=R_hip[1])
+
+
+@pytest.mark.parametrize("case", [
+    dict(P=100000, F=32, W=128, H=128, neg=True, bg=(0.0, 0.0, 0.0), seed=0, cam_index=0),  # = BASELINE configs[2]
+    dict(P=500000, F=32, W=256, H=256, neg=True, bg=(0.0, 0.0, 0.0), seed=0),               # = BASELINE configs[4] shape
+    dict(P=100000, F=3, W=128, H=128, neg=True, bg=(0.0, 0.0, 0.0), seed=12),               # = BASELINE configs[1]
+], ids=["c3_p100k_f32", "c5_p500k_256_f32", "c2_p100k_f3"])
+def test_live_reference_exact_exp_meets_the_contract_at_every_pixel(case):
+    """with fast_exp = 0 the render kernels evaluate exp() with the SAME ocml expf, built by the
+    SAME compiler, as the reference's kernels -- the three hard per-pair decisions (RAST/cuda_rasterizer/forward.cu:345-361)
+    then see bit-identical alphas.  No fragile allowance: EVERY pixel within the 1e-4 contract (zero pixels above it), every
+    gradient row within 1e-3 of the tensor's max."""
+    from oracle import ref_cuda
+    if not ref_cuda.available(case["F"]):
+        pytest.skip("oracle/_ref/libmgs_ref*.so not built (needs /root/reference at build time)")
+    sc, cam, kw, dC, dF = util.scene_case(**case)
+    cr, fr, rr, gr, R = util.run_reference(sc, kw, dC, dF)
+    old = _lib.get_option("fast_exp")
+    try:
+        _lib.set_option("fast_exp", 0)
+        ch, fh, rh, gh = util.run_hip(sc, cam, dC, dF, 1, True, case.get("bg", (0.1, 0.2, 0.3)))
+    finally:
+        _lib.set_option("fast_exp", old)
+    assert np.array_equal(np.asarray(rh), np.asarray(rr))
+    stats = {}
+    for nm, a, b in (("color", ch, cr), ("feature", fh, fr)):
+        e = np.abs(np.asarray(a) - np.asarray(b)).max(0)
+        stats[nm] = dict(max=float(e.max()), pixels_above_1e_4=int((e > IMG_TOL).sum()), pixels_above_2e_5=int((e > 2e-5).sum()))
+    for k, v in gh.items():
+        r = np.asarray(gr[util.GRAD_KEYS[k]])
+        if r.size:
+            e = np.abs(v.numpy() - r.reshape(v.shape)).reshape(v.shape[0], -1).max(1)
+            stats["grad_" + k] = dict(max_rel=float(e.max() / (np.abs(r).max() + 1e-30)))
+    util.report(repr(case), against="reference kernels, fast_exp = 0", **stats)
+    for nm in ("color", "feature"):
+        assert stats[nm]["pixels_above_1e_4"] == 0 and stats[nm]["max"] <= IMG_TOL, (nm, stats[nm])
+    for k, v in stats.items():
+        if k.startswith("grad_"):
+            assert v["max_rel"] <= GRAD_TOL, (k, v)
 
 
 def _num_rendered(sc, cam, case, tight):

@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import manigaussian_amd as mg  # noqa: E402
+
+mg.set_forward_mode("async")  # graph capture needs forwards that never synchronise (opt-in; the default is "safe")
 import util  # noqa: E402
 from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 from manigaussian_amd import synthetic as syn  # noqa: E402
