@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import util  # noqa: E402
 import manigaussian_amd  # noqa: E402
 
-manigaussian_amd.set_forward_mode("blocking")  # every case is another scene of a recurring shape: no workspace guessing
+# (every case is another scene of a recurring shape: the package's default "safe" forward mode never sizes a workspace from
+#  an earlier scene, so nothing is set here -- a module-level set_forward_mode() used to leak into the importing test session)
+assert manigaussian_amd.forward_mode() in ("safe", "blocking"), "the sweep needs a forward mode that cannot overflow"
 
 IMG_TOL, GRAD_TOL = 1e-4, 1e-3
 

@@ -105,15 +105,20 @@ def grad_errors(g_hip, g_ref):
 # alpha*T*|c| <= |c|/255 ~ 4e-3 (alpha threshold) or ~1e-4*|c| (T threshold).
 #  * against ORACLE B (gcc on the host: another exp(), other FMA contraction) such flips are routine: the pixels / Gaussians
 #    Oracle B itself marks as sitting within 2e-5 (relative) of a threshold get FRAGILE_TOL, everything else the contract.
-#  * against the REFERENCE'S OWN KERNELS on the same GPU the only difference is v_exp_f32 vs ocml expf (2e-7 relative):
-#    measured worst fragile pixel 1.06e-4.  There the bound on marked pixels is REF_FRAGILE_TOL = 5e-4
-#    (~5x the worst case seen), unmarked pixels stay at 2e-5, and the NUMBER of pixels above the 1e-4 contract is capped
-#    by a count (a handful), not by a fraction of the image.
+#  * against the REFERENCE'S OWN KERNELS on the same GPU two things differ: v_exp_f32 vs ocml expf (2e-7 relative), and the
+#    ASSOCIATION of the transmittance product -- the reference multiplies (1 - alpha) pair by pair, the chunk-parallel forward
+#    multiplies per-chunk products into the transmittance entering a chunk (then walks the chunk sequentially): the same
+#    real number, another last bit, and T (1 - alpha) < 1e-4 is a hard decision.  Round 4 measured both
+#    (test_live_reference_exact_exp_*): at 100 000 Gaussians / 128^2 no pixel differs by more than 9.5e-7 under EITHER exp;
+#    at 500 000 / 256^2 (~1e9 pairs) ONE pixel flips its stop decision -- the same pixel, the same 1.16e-4 / 2.03e-4, under
+#    v_exp_f32 AND under ocml expf: the exp is not the cause, the product association is.  Bounds: unmarked pixels 2e-5, a
+#    marked pixel REF_FRAGILE_TOL = 2.5e-4, at most ONE pixel of an image above the 1e-4 contract; gradients meet the
+#    contract (1e-3 of the max) everywhere, marked or not (measured <= 5.7e-4).
 FRAGILE_TOL = 1e-2
 FRAGILE_MAX_FRACTION = 0.02
-REF_FRAGILE_TOL = 5e-4
-REF_FRAGILE_GRAD_TOL = 3e-3
-REF_MAX_PIXELS_ABOVE_CONTRACT = 8
+REF_FRAGILE_TOL = 2.5e-4
+REF_FRAGILE_GRAD_TOL = 1e-3
+REF_MAX_PIXELS_ABOVE_CONTRACT = 1
 
 
 def report(tag, **stats):
