@@ -81,6 +81,66 @@ def _fill_args(a, *, P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefilt
     a.img, a.img_bytes = _ptr(img), 0 if img is None else img.numel()
 
 
+# ---- host-side caches: everything that is a pure function of the problem shape is computed once --------------------------------
+_SIZES = {}      # (P, M, W, H) -> (geom bytes, img bytes), both rounded up to 256
+_BIN_BYTES = {}  # (cap, pool, W, H, F) -> binning bytes
+_WORST = {}      # (P, W, H, F, safe_bytes) -> (cannot_overflow, cap_worst, pool_worst)
+_LAYOUTS = {}    # (P, M, F) -> (sizes, accum_bytes)
+_TEMPLATES = {}  # shape + settings scalars + options version -> bytes of a pre-filled MgsRasterArgs
+_EMPTY_U8 = {}   # device -> an empty uint8 tensor (placeholder for workspaces that live in another tensor's arena)
+_SPLIT_WORKSPACES = False  # testing: geom / img / binning as three allocations (guard bands behind each, tests/test_gpu_parity.py)
+
+
+def _up256(n):
+    return (n + 255) & ~255
+
+
+def _shape_sizes(L, P, M, W, H):
+    k = (P, M, W, H)
+    v = _SIZES.get(k)
+    if v is None:
+        v = _SIZES[k] = (_up256(L.mgs_geom_bytes(P, M, W, H)), _up256(L.mgs_img_bytes(W, H)))
+    return v
+
+
+def _bin_bytes(L, cap, pool, W, H, F):
+    k = (cap, pool, W, H, F)
+    v = _BIN_BYTES.get(k)
+    if v is None:
+        if len(_BIN_BYTES) > 4096:
+            _BIN_BYTES.clear()
+        v = _BIN_BYTES[k] = L.mgs_binning_bytes2(cap, pool, W, H, F)
+    return v
+
+
+def _worst_case(L, P, W, H, F, T):
+    budget = _state.safe_bytes()
+    k = (P, W, H, F, budget)
+    v = _WORST.get(k)
+    if v is None:
+        cap_worst = P * T  # every Gaussian in every tile
+        ok = cap_worst < (1 << 30) and L.mgs_binning_bytes2(cap_worst, 0, W, H, F) <= budget
+        v = _WORST[k] = (ok, cap_worst, L.mgs_chunk_pool_max(cap_worst, W, H) if ok else 0)
+    return v
+
+
+def _template(P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefiltered, debug, include_feature):
+    """A MgsRasterArgs with every field that does not change from call to call already filled (shape, camera scalars,
+    options); _forward copies it and sets the pointers."""
+    k = (P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefiltered, debug, include_feature, _lib.OPTIONS_VERSION[0])
+    t = _TEMPLATES.get(k)
+    if t is None:
+        if len(_TEMPLATES) > 512:
+            _TEMPLATES.clear()
+        a = _lib.MgsRasterArgs()
+        a.P, a.D, a.M, a.F, a.W, a.H = P, D, M, F, W, H
+        a.tanfovx, a.tanfovy, a.scale_modifier = tanfovx, tanfovy, scale_modifier
+        a.prefiltered, a.debug, a.include_feature = int(bool(prefiltered)), int(bool(debug)), int(bool(include_feature))
+        opts = _lib.fill_options(a)
+        t = _TEMPLATES[k] = (bytes(a), opts)
+    return t
+
+
 class ForwardHandle:
     """What a forward leaves for its backward: the filled MgsRasterArgs (reused, not rebuilt), the per-call options and
     the pending device report.  int(handle) blocks until the instance count is known (the reference returns it as an int)."""
@@ -181,10 +241,28 @@ def _grad_layout(L, P, M, F):
     scales | rotations | cov3D | means2D | pad].  The first three regions are the accumulators; the gradients of the
     Gaussian PARAMETERS (colours or SH, features, means, opacity, scales, rotations) are contiguous, so one all-reduce
     over the span they cover (parallel.flat_alias) moves nothing else."""
-    scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
-    sizes = [scratch_f, 3 * P, F * P, 3 * P, P, 3 * M * P, 3 * P, 4 * P, 6 * P, 3 * P, 4]
-    accum_bytes = ((scratch_f + 3 * P + F * P) * 4 + 15) // 16 * 16  # may reach into the next, fully rewritten, region
-    return sizes, accum_bytes
+    k = (P, M, F)
+    v = _LAYOUTS.get(k)
+    if v is None:
+        scratch_f = (L.mgs_backward_scratch_bytes(P, M, F) + 3) // 4
+        sizes = [scratch_f, 3 * P, F * P, 3 * P, P, 3 * M * P, 3 * P, 4 * P, 6 * P, 3 * P, 4]
+        accum_bytes = ((scratch_f + 3 * P + F * P) * 4 + 15) // 16 * 16  # may reach into the next, fully rewritten, region
+        v = _LAYOUTS[k] = (sizes, accum_bytes)
+    return v
+
+
+def _grad_offsets(L, P, M, F):
+    """(float offsets of the regions of _grad_layout, total floats)."""
+    k = (P, M, F, "offs")
+    v = _LAYOUTS.get(k)
+    if v is None:
+        sizes, _ = _grad_layout(L, P, M, F)
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += n
+        v = _LAYOUTS[k] = (tuple(offs), o)
+    return v
 
 
 def rasterize_gaussians(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
@@ -250,18 +328,13 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         capturing = _capturing()
         if not capturing:
             st.drain()  # reports of earlier forwards that have arrived: learn their counts, raise if one overflowed
-        out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
-        out_feat = torch.empty((F, H, W), dtype=_F32, device=dev) if include_feature else \
-            torch.zeros((1,), dtype=_F32, device=dev)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)  # written for every Gaussian by the preprocess
-        opts = dict(_lib.DEFAULT_OPTIONS)
+        # everything that is a function of the shape alone comes from caches (sizes, the pre-filled argument struct)
+        tmpl, opts = _template(P, int(degree), M, F, W, H, float(tan_fovx), float(tan_fovy), float(scale_modifier),
+                               bool(prefiltered), bool(debug), include_feature)
         key = (P, W, H, F, opts["tight_bins"])
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        guess = st.guess(key)
-        cap_worst = P * T  # every Gaussian in every tile
-        cannot_overflow = cap_worst < (1 << 30) and L.mgs_binning_bytes2(cap_worst, 0, W, H, F) <= _state.safe_bytes()
-        if cannot_overflow:
-            guess = (cap_worst, L.mgs_chunk_pool_max(cap_worst, W, H))  # no marks, no warm-up call needed
+        cannot_overflow, cap_worst, pool_worst = _worst_case(L, P, W, H, F, T)
+        guess = (cap_worst, pool_worst) if cannot_overflow else st.guess(key)  # worst case: no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and
                 _state.lazy_allowed(cannot_overflow) and opts["bin_mode"] == 1 and T <= 4096)
@@ -274,23 +347,41 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         else:  # blocking path: the chunk pool is the worst case for the capacity (cannot overflow)
             m = st.marks.get(key)
             cap, pool = (m[0] + m[0] // 4 + 4096 if m else 4 * P + 4096), 0
-        geom = torch.empty((L.mgs_geom_bytes(P, M, W, H),), **u8)
-        img = torch.empty((L.mgs_img_bytes(W, H),), **u8)
-        binning = torch.empty((L.mgs_binning_bytes2(cap, pool, W, H, F),), **u8)
-        a = _lib.MgsRasterArgs()
-        _fill_args(a, P=P, D=int(degree), M=M, F=F, W=W, H=H, tanfovx=float(tan_fovx), tanfovy=float(tan_fovy),
-                   scale_modifier=float(scale_modifier), prefiltered=prefiltered, debug=debug,
-                   include_feature=include_feature, background=background, means3D=means3D, sh=sh, colors=colors,
-                   language_feature=language_feature, opacity=opacity, scales=scales, rotations=rotations,
-                   cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos,
-                   geom=geom, binning=binning, img=img)
-        _lib.fill_options(a, opts)
+        # ONE allocation for the three opaque workspaces [geom | img | binning] (each a multiple of 256 bytes), one for the
+        # two images; radii and the backward's gradient buffer have lifetimes of their own
+        gb, ib = _shape_sizes(L, P, M, W, H)
+        bb = _bin_bytes(L, cap, pool, W, H, F)
+        if _SPLIT_WORKSPACES:
+            ws3 = (torch.empty((gb,), **u8), torch.empty((ib,), **u8), torch.empty((bb,), **u8))
+            p_geom, p_img, p_bin = ws3[0].data_ptr(), ws3[1].data_ptr(), ws3[2].data_ptr()
+            ws = None
+        else:
+            ws = torch.empty((gb + ib + bb,), **u8)
+            p_geom = ws.data_ptr()
+            p_img, p_bin = p_geom + gb, p_geom + gb + ib
+        if include_feature:
+            out = torch.empty((3 + F, H, W), dtype=_F32, device=dev)
+            out_color, out_feat = out[:3], out[3:]
+        else:
+            out_color = torch.empty((3, H, W), dtype=_F32, device=dev)
+            out_feat = torch.zeros((1,), dtype=_F32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)  # written for every Gaussian by the preprocess
+        a = _lib.MgsRasterArgs.from_buffer_copy(tmpl)
+        a.background, a.means3D, a.shs, a.colors_precomp = _ptr(background), means3D.data_ptr(), _ptr(sh), _ptr(colors)
+        a.language_feature = language_feature.data_ptr() if include_feature else None
+        a.opacities, a.scales, a.rotations, a.cov3D_precomp = _ptr(opacity), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+        a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
+        a.geom, a.geom_bytes, a.img, a.img_bytes = p_geom, gb, p_img, ib
+        a.binning, a.binning_bytes = p_bin, bb
         slot_ptr, tag = st.take_slot()
         # The blocking path leaves binning_capacity at 0: the library then derives the carving from the buffer's BYTE COUNT,
         # which is all a caller of the reference-shaped pair rasterize_gaussians / rasterize_gaussians_backward(R: int,
         # binningBuffer) hands back -- forward and backward agree by construction.  The asynchronous path names (capacity,
         # pool) explicitly and its backward reuses this very struct (ForwardHandle.a).
-        a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = (cap, pool, tag, 1) if lazy else (0, 0, tag, 0)
+        if lazy:
+            a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = cap, pool, tag, 1
+        else:
+            a.status_tag = tag
         grad_buffer = None
         if want_grad_buffer:
             sizes, accum_bytes = _grad_layout(L, P, M, F)
@@ -300,10 +391,11 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         feat_ptr = out_feat.data_ptr() if include_feature else None
         rc, R = _launch_forward(L, a, None, radii, out_color, out_feat, slot_ptr, stream)
         pending = None
+        binning2 = None
         if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) first call for this shape, or the scene grew: bin + render again
             cap = R + R // 4 + 4096
-            binning = torch.empty((L.mgs_binning_bytes2(cap, 0, W, H, F),), **u8)
-            a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning.data_ptr(), binning.numel(), 0, 0
+            binning2 = torch.empty((L.mgs_binning_bytes2(cap, 0, W, H, F),), **u8)
+            a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning2.data_ptr(), binning2.numel(), 0, 0
             rc = L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(), feat_ptr,
                                                 stream)
             _lib.check(rc, "rasterize_gaussians")
@@ -318,6 +410,16 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         handle = ForwardHandle(a, opts, pending, R, (background, means3D, sh, colors, language_feature, opacity, scales,
                                                      rotations, cov3D_precomp, viewmatrix, projmatrix, campos),
                                outs=(_weak(out_color), _weak(out_feat) if include_feature and F == F_user else None))
+        if ws is None:
+            geom, img, binning = ws3[0], ws3[1], (binning2 if binning2 is not None else ws3[2])
+        elif blocking:  # the reference-shaped triple: three tensors whose byte counts describe their carving
+            geom, img = ws[:gb], ws[gb:gb + ib]
+            binning = binning2 if binning2 is not None else ws[gb + ib:]
+        else:         # the autograd path keeps ONE tensor alive (the backward reads the addresses from the handle)
+            e = _EMPTY_U8.get(dev)
+            if e is None:
+                e = _EMPTY_U8[dev] = torch.empty((0,), **u8)
+            geom, img, binning = ws, e, (binning2 if binning2 is not None else e)
     if include_feature and F != F_user:
         out_feat = out_feat[:F_user].contiguous()
     return handle, out_color, out_feat, radii, geom, binning, img, grad_buffer
@@ -382,12 +484,12 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
                     z(0, M, 3), z(0, 3), z(0, 4))
         # ONE allocation for the scratch accumulators and every gradient: the three regions the render backward
         # accumulates into (acc8 | dL_dcolors | dL_dfeature) come first and are contiguous, so the library zeroes
-        # them with a single fill; everything else is fully written by the kernels.
-        sizes, _ = _grad_layout(L, P, M, F)
-        prezeroed = grad_buffer is not None and grad_buffer.numel() == sum(sizes)
-        flat = grad_buffer if prezeroed else torch.empty((sum(sizes),), dtype=_F32, device=dev)
-        (scratch, g_colors, g_feat, g_means3D, g_opacity, g_sh, g_scales, g_rot, g_cov3D, g_means2D,
-         _pad) = flat.split_with_sizes(sizes)
+        # them with a single fill; everything else is fully written by the kernels.  Regions are addressed by offset
+        # (no split / view tensors on the way in; one as_strided per gradient on the way out).
+        (o_scr, o_col, o_feat, o_m3, o_op, o_sh, o_sc, o_rot, o_cov, o_m2, _o_pad), total = _grad_offsets(L, P, M, F)
+        prezeroed = grad_buffer is not None and grad_buffer.numel() == total
+        flat = grad_buffer if prezeroed else torch.empty((total,), dtype=_F32, device=dev)
+        base = flat.data_ptr()
         if handle is not None:  # the forward's arguments, as they were (same tensors: they are saved in the autograd ctx)
             a = handle.a
             count = handle.num_rendered_nowait()
@@ -418,16 +520,20 @@ def _backward(background, means3D, radii, colors, language_feature, scales, rota
         a.accum_prezeroed = 1 if prezeroed else 0
         _lib.check(L.mgs_rasterize_backward(
             ctypes.byref(a), count, radii.data_ptr(), dL_dout_color.data_ptr(),
-            _ptr(dL_dout_language_feature) if include_feature else None, g_means2D.data_ptr(), None,
-            g_opacity.data_ptr(), g_colors.data_ptr(), _ptr(g_feat) if include_feature else None,
-            g_means3D.data_ptr(), g_cov3D.data_ptr(), _ptr(g_sh), g_scales.data_ptr(), g_rot.data_ptr(),
-            scratch.data_ptr(), scratch.numel() * 4, _stream(dev)), "rasterize_gaussians_backward")
-        g_feat = g_feat.view(P, F) if include_feature else torch.zeros((1,), dtype=_F32, device=dev)
+            _ptr(dL_dout_language_feature) if include_feature else None, base + 4 * o_m2, None,
+            base + 4 * o_op, base + 4 * o_col, (base + 4 * o_feat) if include_feature else None,
+            base + 4 * o_m3, base + 4 * o_cov, (base + 4 * o_sh) if M else None, base + 4 * o_sc, base + 4 * o_rot,
+            base + 4 * o_scr, (o_col - o_scr) * 4, _stream(dev)), "rasterize_gaussians_backward")
+        view = flat.as_strided
+        g_feat = view((P, F), (F, 1), o_feat) if include_feature else torch.zeros((1,), dtype=_F32, device=dev)
+        g_sh = view((P, M, 3), (3 * M, 3, 1), o_sh) if M else flat.new_empty((P, 0, 3))
+        out = (view((P, 3), (3, 1), o_m2), view((P, 3), (3, 1), o_col), g_feat, view((P, 1), (1, 1), o_op),
+               view((P, 3), (3, 1), o_m3), view((P, 6), (6, 1), o_cov), g_sh, view((P, 3), (3, 1), o_sc),
+               view((P, 4), (4, 1), o_rot))
     del keep
     if include_feature and F != F_user:
-        g_feat = g_feat[:, :F_user].contiguous()
-    return (g_means2D.view(P, 3), g_colors.view(P, 3), g_feat, g_opacity.view(P, 1), g_means3D.view(P, 3),
-            g_cov3D.view(P, 6), g_sh.view(P, M, 3), g_scales.view(P, 3), g_rot.view(P, 4))
+        out = out[:2] + (out[2][:, :F_user].contiguous(),) + out[3:]
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

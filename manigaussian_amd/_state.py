@@ -37,6 +37,7 @@ from . import _lib
 
 NSLOTS = 1024  # status slots per device (two 64-bit words each); far more than forwards can be in flight
 
+_WORDS = {}  # slot pointer -> (numpy view of its device's status block, index of the slot's first word)
 _MODE = os.environ.get("MGS_FORWARD_MODE", "safe")  # "safe" | "async" | "blocking"
 _STATES = {}
 _LOCK = threading.Lock()
@@ -102,10 +103,11 @@ def set_headroom(instances: float = None, chunks: float = None):
 class Pending:
     """One forward whose device report has not been read yet."""
     __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured", "recoverable", "recovered",
-                 "backward_enqueued", "tag", "cap", "pool")
+                 "backward_enqueued", "tag", "cap", "pool", "words")
 
     def __init__(self, a, V, slot_ptr, key, captured=False, recoverable=False):
         self.a, self.V, self.slot_ptr, self.key = a, V, slot_ptr, key
+        self.words = _WORDS.get(slot_ptr)  # (numpy view of the status block, index of word 0) for a cheap "anything yet?"
         self.num_rendered = self.chunks_used = -1
         self.rc = _lib.MGS_PENDING
         self.captured = captured
@@ -120,6 +122,9 @@ class Pending:
         if self.rc != _lib.MGS_PENDING:
             return self.rc
         if self.recovered:  # its arguments describe the re-run now; this run's verdict is in
+            return self.rc
+        w = self.words
+        if w is not None and w[0][w[1]] == -1 and w[0][w[1] + 1] == -1:  # both words still "pending": no call into the library
             return self.rc
         L = _lib.lib()
         nr, ch = ctypes.c_int32(-1), ctypes.c_int32(-1)
@@ -141,6 +146,10 @@ class DeviceState:
         self.dev = dev
         self.status = torch.full((2 * NSLOTS,), -1, dtype=torch.int64).pin_memory()
         self.base_ptr = self.status.data_ptr()
+        words = self.status.numpy()
+        for i in range(NSLOTS):
+            _WORDS[self.base_ptr + 16 * i] = (words, 2 * i)
+        self.reserved = set()  # slots held by captured graphs
         self.next_slot = 0
         self.marks = {}      # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
         self.pending = collections.deque()
@@ -151,24 +160,26 @@ class DeviceState:
     def take_slot(self):
         """(pointer to two pinned words, tag) for one forward."""
         with self.lock:
-            reserved = {p.slot_ptr for p in self.captured}
+            reserved = self.reserved
             for _ in range(NSLOTS):
                 i = self.next_slot
                 self.next_slot = (i + 1) % NSLOTS
                 ptr = self.base_ptr + 16 * i
-                if ptr not in reserved:
+                if not reserved or ptr not in reserved:
                     break
             else:
                 raise RuntimeError("all status slots are held by captured graphs")
-        with _LOCK:
-            _TAG[0] = (_TAG[0] + 1) & 0xffff
-            tag = _TAG[0]
+            _TAG[0] = tag = (_TAG[0] + 1) & 0xffff  # (unique per in-flight forward of this device is all that is needed)
         return ptr, tag
 
     def add(self, pending):
         """Register a forward whose report is outstanding (thread-safe: ctypes calls release the GIL)."""
         with self.lock:
-            (self.captured if pending.captured else self.pending).append(pending)
+            if pending.captured:
+                self.captured.append(pending)
+                self.reserved.add(pending.slot_ptr)
+            else:
+                self.pending.append(pending)
 
     # ---- high-water marks ---------------------------------------------------------------------------------------
     def guess(self, key):

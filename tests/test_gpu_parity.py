@@ -732,7 +732,7 @@ def test_live_reference_exact_exp_and_fast_exp_sit_equally_close(case):
         same pixel, the same value.  What differs from the reference there is the association of the transmittance
         product (per-chunk products vs the reference's pair-by-pair chain): a last-bit difference in T at one
         T (1 - alpha) < 1e-4 stop decision.  Asserted: the two exps leave the SAME set of pixels above 2e-5, at most one
-        pixel above 1e-4, none above 2.5e-4; gradients within the 1e-3 contract everywhere."""
+        pixel above 1e-4, none above util.REF_FRAGILE_TOL; gradients within the 1e-3 contract everywhere."""
     from oracle import ref_cuda
     if not ref_cuda.available(case["F"]):
         pytest.skip("oracle/_ref/libmgs_ref*.so not built (needs /root/reference at build time)")
@@ -1049,6 +1049,7 @@ def test_view_batch_workspaces_are_not_overrun(P, V, W, monkeypatch):
     gt = _GuardedTorch()
     monkeypatch.setattr(views_mod, "torch", gt)
     monkeypatch.setattr(C_mod, "torch", gt)
+    monkeypatch.setattr(C_mod, "_SPLIT_WORKSPACES", True)  # three allocations instead of one arena: a guard band behind each
     F = 32
     sc, cams, dC, dF = _batch_case(P, F, V, W, W)
     cb, fb, rb, grads, m2g = _run_batch(sc, cams, dC, dF, (0.1, 0.2, 0.3))
