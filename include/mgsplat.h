@@ -58,7 +58,7 @@ typedef struct MgsOptions {
   int32_t fast_exp;     /* 1*: v_exp_f32-based exp in the render kernels (rel. error ~2e-7 |x|); 0: ocml expf      */
   int32_t exact_cull;   /* 1*: exact ellipse-vs-block test on top of the bounding-box test in the render forward   */
   int32_t bin_mode;     /* 1*: histogram + scatter + LDS segment sort + rank merge; 0: rocPRIM scan + radix sort   */
-  int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048)                                     */
+  int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048, 4096: for lists of >> 8192 per tile)  */
   int32_t gm_waves;     /* 16*: waves per workgroup of the render backward (8 or 16)                               */
   int32_t dbg;          /* 0*: diagnostics of the render forward (256: phase timeline, mgs_debug_read_trace)       */
 } MgsOptions;

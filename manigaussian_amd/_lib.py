@@ -166,8 +166,8 @@ def set_option(key: str, value: int):
     if key == "profile":
         check(lib().mgs_set_option(key.encode(), int(value)), "mgs_set_option")
     elif key in DEFAULT_OPTIONS:
-        if key == "seg" and int(value) not in (512, 1024, 2048):
-            raise RuntimeError("seg must be 512, 1024 or 2048")
+        if key == "seg" and int(value) not in (512, 1024, 2048, 4096):
+            raise RuntimeError("seg must be 512, 1024, 2048 or 4096")
         DEFAULT_OPTIONS[key] = int(value)
         OPTIONS_VERSION[0] += 1
     else:

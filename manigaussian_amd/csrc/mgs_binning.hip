@@ -355,6 +355,128 @@ __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* _
   if (e0 + 1u < cnt) keys[base + e0 + 1u] = k1;
 }
 
+// ---- bitonic sort of one 4096-key segment: FOUR keys per lane (MgsOptions.seg = 4096, an option) -------------
+// Element e lives in thread e / 4, slot e % 4.  Compare-exchange distance j: 1, 2 = inside the thread; 4 .. 128 = lane
+// distance j / 4 inside the wave; >= 256 = through LDS, TWO stages per round trip: a thread picks up the elements
+// {x, x+J, x+2J, x+3J} (x without the bits J and 2J), which hold the pairs of stage 2J and of stage J.
+// Round 4 measured this family against the two-keys-per-lane kernel above (profiles/r04_exp_segsort.log): four keys per lane
+// on 512 threads for 2048-key segments: 15.4 us against 13.2 at BASELINE configs[2], 77 us against 65 at the configs[4]
+// shape (the network is latency-bound: more live waves hide more of it); two keys per lane with paired LDS round trips:
+// 14.3 / 74 us.  Neither replaced the kernel above; 4096-key segments halve the rank merge's work on long lists (58 -> 38 us
+// at the configs[4] shape) for a slower sort (65 -> 77 us) -- 115 us against 123 in all, kept as an option.
+// The index arithmetic was checked against a CPU emulation for every segment-length class.
+__device__ __forceinline__ void ce_regs(uint64_t& a, uint64_t& b, bool up) {
+  const bool lt = a < b;
+  const uint64_t lo = lt ? a : b, hi = lt ? b : a;
+  a = up ? lo : hi;
+  b = up ? hi : lo;
+}
+template <int D, int KPT>
+__device__ __forceinline__ void ce_lanes(uint64_t (&k)[KPT], bool up, int lane) {
+  const bool keep_min = ((lane & D) == 0) == up;
+#pragma unroll
+  for (int s = 0; s < KPT; s++) {
+    const uint64_t p = lane_xor64<D>(k[s], lane);
+    k[s] = ((k[s] < p) == keep_min) ? k[s] : p;
+  }
+}
+
+template <int SEGN, int KPT>
+__global__ void __launch_bounds__(SEGN / KPT) bin_segsort4_kernel(const uint32_t* __restrict__ n_seg,
+                                                                  const uint4* __restrict__ seg_desc,
+                                                                  const uint64_t* __restrict__ keys_unsorted,
+                                                                  uint64_t* __restrict__ keys,
+                                                                  uint32_t* __restrict__ point_list) {
+  static_assert(KPT == 2 || KPT == 4, "two or four keys per lane");
+  constexpr uint32_t NT = SEGN / KPT;
+  constexpr uint32_t LDS_MIN = 64u * KPT;  // smallest compare-exchange distance that crosses waves
+  __shared__ uint64_t sk[SEGN];
+  const uint32_t tid = threadIdx.x;
+  const int lane = (int)(tid & 63u);
+  const uint4 d = seg_desc[blockIdx.x];  // surplus workgroups read an unused (in-bounds) entry
+  const uint32_t nseg = *n_seg;
+  if (blockIdx.x >= nseg) return;
+  const uint32_t cnt = d.y;
+  const size_t base = d.x;
+  uint32_t n = LDS_MIN;
+  while (n < cnt) n <<= 1;
+  const uint32_t e0 = (uint32_t)KPT * tid;
+  const bool mine = e0 < n;  // threads past the padded length hold padding only
+  uint64_t k[KPT];
+#pragma unroll
+  for (int s = 0; s < KPT; s++) k[s] = e0 + (uint32_t)s < cnt ? keys_unsorted[base + e0 + (uint32_t)s] : ~0ull;
+  for (uint32_t kk = 2; kk <= n; kk <<= 1) {
+    uint32_t j = kk >> 1;
+    if (j >= LDS_MIN) {
+      if (mine) {
+#pragma unroll
+        for (int s = 0; s < KPT; s++) sk[e0 + (uint32_t)s] = k[s];
+      }
+      while (j >= LDS_MIN) {
+        const bool two = (j >> 1) >= LDS_MIN;
+        const uint32_t J = two ? (j >> 1) : j;
+        __syncthreads();
+        if (two) {  // stages 2J and J (kk = 4J: one direction for the four elements of a group)
+          for (uint32_t g = tid; g < (n >> 2); g += NT) {
+            const uint32_t x = ((g & ~(J - 1u)) << 2) | (g & (J - 1u));
+            uint64_t a0 = sk[x], a1 = sk[x + J], a2 = sk[x + 2u * J], a3 = sk[x + 3u * J];
+            const bool up = (x & kk) == 0u;
+            ce_regs(a0, a2, up); ce_regs(a1, a3, up);
+            ce_regs(a0, a1, up); ce_regs(a2, a3, up);
+            sk[x] = a0; sk[x + J] = a1; sk[x + 2u * J] = a2; sk[x + 3u * J] = a3;
+          }
+        } else {    // stage J alone
+          for (uint32_t c = tid; c < (n >> 1); c += NT) {
+            const uint32_t x = ((c & ~(J - 1u)) << 1) | (c & (J - 1u));
+            uint64_t a0 = sk[x], a1 = sk[x + J];
+            ce_regs(a0, a1, (x & kk) == 0u);
+            sk[x] = a0; sk[x + J] = a1;
+          }
+        }
+        j = J >> 1;
+      }
+      __syncthreads();
+      if (mine) {
+#pragma unroll
+        for (int s = 0; s < KPT; s++) k[s] = sk[e0 + (uint32_t)s];
+      }
+    }
+    if (kk >= 2u * KPT) {  // lane distances j / KPT = 32 .. 1
+      const bool up = (e0 & kk) == 0u;  // one direction for the thread's slots
+      switch (j / (uint32_t)KPT) {
+        case 32: ce_lanes<32, KPT>(k, up, lane); [[fallthrough]];
+        case 16: ce_lanes<16, KPT>(k, up, lane); [[fallthrough]];
+        case 8: ce_lanes<8, KPT>(k, up, lane); [[fallthrough]];
+        case 4: ce_lanes<4, KPT>(k, up, lane); [[fallthrough]];
+        case 2: ce_lanes<2, KPT>(k, up, lane); [[fallthrough]];
+        case 1: ce_lanes<1, KPT>(k, up, lane); [[fallthrough]];
+        default: break;
+      }
+    }
+    // distances below KPT: inside the thread
+    if constexpr (KPT == 4) {
+      if (kk >= 4u) {
+        const bool up = (e0 & kk) == 0u;
+        ce_regs(k[0], k[2], up); ce_regs(k[1], k[3], up);
+        ce_regs(k[0], k[1], up); ce_regs(k[2], k[3], up);
+      } else {  // kk == 2: elements 4t, 4t+1 ascending, 4t+2, 4t+3 descending
+        ce_regs(k[0], k[1], true); ce_regs(k[2], k[3], false);
+      }
+    } else {
+      ce_regs(k[0], k[1], (e0 & kk) == 0u);
+    }
+  }
+  if (cnt == d.w) {  // the slice is this one segment: sorted ids go straight out, the merge kernel skips it
+#pragma unroll
+    for (int s = 0; s < KPT; s++)
+      if (e0 + (uint32_t)s < cnt) point_list[base + e0 + (uint32_t)s] = (uint32_t)k[s];
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < KPT; s++)
+    if (e0 + (uint32_t)s < cnt) keys[base + e0 + (uint32_t)s] = k[s];
+}
+
 // lower bounds of two keys in the sorted LDS array a[0..len), len <= SEGN and WAVE-UNIFORM (every lane ranks in the same
 // segment).  Bounded branch-free search: the first probe, at the largest power of two P <= len, picks the window a[0..P) or
 // a[len-P..len) (everything before it is then known to be smaller); log2 P halvings and one last probe finish inside the
@@ -390,14 +512,14 @@ __device__ __forceinline__ void lds_lower_bound2(const uint64_t* a, uint32_t len
 
 // K6': final position of a key = its index + its lower-bound rank in the tile's other segments (keys are unique),
 // staged through LDS in groups of whole segments (<= CAP keys); then emission of the sorted ids.  One workgroup per
-// segment, two keys per thread.  (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores
+// segment, KPT keys per thread.  (A one-workgroup-per-tile variant that emits in output order with fully coalesced stores
 // was measured at 45 us against 19 us for this one at C3: 64 tiles cannot keep 256 CUs busy.)
-template <int SEGN>
-__global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
-                                                                   const uint4* __restrict__ seg_desc,
-                                                                   const uint64_t* __restrict__ keys,
-                                                                   uint32_t* __restrict__ point_list) {
-  constexpr uint32_t NT = SEGN / 2;
+template <int SEGN, int KPT>  // KPT: keys ranked per thread
+__global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32_t* __restrict__ n_seg,
+                                                                     const uint4* __restrict__ seg_desc,
+                                                                     const uint64_t* __restrict__ keys,
+                                                                     uint32_t* __restrict__ point_list) {
+  constexpr uint32_t NT = SEGN / KPT;
   constexpr uint32_t CAP = 8192;  // keys staged per group (64 KB)
   __shared__ uint64_t sk[CAP];
   const uint32_t tid = threadIdx.x;
@@ -416,15 +538,15 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
   const uint32_t ns = div_up_u(L, (uint32_t)SEGN), seglen = div_up_u(L, ns);
   const uint32_t self = (d.x - start) / seglen;
   const uint64_t* __restrict__ tk = keys + start;  // the tile's slice
-  uint64_t key[2];
-  uint32_t rank[2];
+  uint64_t key[KPT];
+  uint32_t rank[KPT];
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
+  for (int e = 0; e < KPT; e++) {
     const uint32_t i = tid + e * NT;
     key[e] = i < cnt ? keys[(size_t)d.x + i] : ~0ull;
     rank[e] = i;
   }
-  const uint32_t per_group = CAP / seglen;  // >= 4 whole segments
+  const uint32_t per_group = CAP / seglen;  // >= 2 whole segments (4 for SEGN <= 2048)
   for (uint32_t s0 = 0; s0 < ns; s0 += per_group) {
     const uint32_t s1 = min(ns, s0 + per_group);
     if (s1 - s0 == 1 && s0 == self) continue;  // the group holds only this workgroup's own segment
@@ -447,14 +569,17 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
     for (uint32_t s2 = s0; s2 < s1; s2++) {
       if (s2 == self) continue;
       const uint32_t o2 = (s2 - s0) * seglen, len = min(seglen, L - s2 * seglen);
-      uint32_t q0, q1;
-      lds_lower_bound2<SEGN>(sk + o2, len, key[0], key[1], q0, q1);
-      rank[0] += q0;
-      rank[1] += q1;
+#pragma unroll
+      for (int e = 0; e < KPT; e += 2) {
+        uint32_t q0, q1;
+        lds_lower_bound2<SEGN>(sk + o2, len, key[e], key[e + 1], q0, q1);
+        rank[e] += q0;
+        rank[e + 1] += q1;
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
+  for (int e = 0; e < KPT; e++) {
     const uint32_t i = tid + e * NT;
     if (i < cnt) point_list[(size_t)start + rank[e]] = (uint32_t)key[e];
   }
@@ -463,11 +588,16 @@ __global__ void __launch_bounds__(SEGN / 2) bin_merge_emit_kernel(const uint32_t
 template <int SEGN>
 static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
-  if (which == 1)
-    hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                       b.keys_unsorted, b.keys, b.point_list);
-  else
-    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / 2), 0, s, im.seg_base + T,  // (XCD map)
+  constexpr int KPT = SEGN > 2048 ? 4 : 2;
+  if (which == 1) {
+    if constexpr (KPT == 4)
+      hipLaunchKernelGGL((bin_segsort4_kernel<SEGN, 4>), dim3(n_segments), dim3(SEGN / 4), 0, s, im.seg_base + T, b.seg_desc,
+                         b.keys_unsorted, b.keys, b.point_list);
+    else
+      hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
+                         b.keys_unsorted, b.keys, b.point_list);
+  } else
+    hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, KPT>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / KPT), 0, s, im.seg_base + T,  // (XCD map)
                        b.seg_desc, b.keys, b.point_list);
 }
 
@@ -487,6 +617,7 @@ hipError_t launch_bin_segsort(int which, const GeomView& g, const BinView& b, co
   switch (seg) {
     case 512: launch_sort_or_merge<512>(which, b, im, R, T, s); break;
     case 1024: launch_sort_or_merge<1024>(which, b, im, R, T, s); break;
+    case 4096: launch_sort_or_merge<4096>(which, b, im, R, T, s); break;
     default: launch_sort_or_merge<2048>(which, b, im, R, T, s); break;
   }
   return hipGetLastError();

@@ -155,7 +155,7 @@ def test_parity_with_oracle(name, tight):
 _DEFAULTS = dict(gm_waves=16, bin_mode=1, seg=2048, exact_cull=1, fast_exp=1, tight_bins=1)
 VARIANTS = {
     "rocprim_binning": dict(bin_mode=0),
-    "segments_512": dict(seg=512), "segments_1024": dict(seg=1024),
+    "segments_512": dict(seg=512), "segments_1024": dict(seg=1024), "segments_4096": dict(seg=4096),
     "backward_8_waves": dict(gm_waves=8),
     "ocml_expf_bbox_cull": dict(fast_exp=0, exact_cull=0),
 }
@@ -174,13 +174,15 @@ def test_kernel_variants_agree_with_oracle(name):
             _lib.set_option(k, v)
 
 
-@pytest.mark.parametrize("P", [520, 700, 1030, 1300, 1540, 2100, 2570, 4100])
-def test_merge_rank_search_over_segment_lengths(P):
-    """One tile, 512-key segments: the tile's list is cut into 2..8 segments of many different lengths (powers of two, one
-    more, one less, a short last segment) and every key is ranked in the others by the bounded branch-free search of
-    bin_merge_emit_kernel; the sorted order must be the oracle's (images and gradients follow from it)."""
+@pytest.mark.parametrize("seg,P", [(512, 520), (512, 700), (512, 1030), (512, 1300), (512, 1540), (512, 2100), (512, 2570),
+                                   (512, 4100), (2048, 4200), (2048, 9000), (4096, 4200), (4096, 9000), (4096, 13000)])
+def test_merge_rank_search_over_segment_lengths(seg, P):
+    """One tile: its list is cut into 2..8 segments of many different lengths (powers of two, one more, one less, a short
+    last segment), each sorted by the four-keys-per-lane bitonic network (LDS round trips at every segment size), and every
+    key is ranked in the others by the bounded branch-free search of bin_merge_emit_kernel; the sorted order must be the
+    oracle's (images and gradients follow from it)."""
     try:
-        _lib.set_option("seg", 512)
+        _lib.set_option("seg", seg)
         _check(dict(P=P, F=3, W=16, H=16, neg=False))
     finally:
         _lib.set_option("seg", _DEFAULTS["seg"])
