@@ -227,17 +227,17 @@ KERNELS = [("preprocess_fwd", "preprocess_fwd_kernel", "K2 forward preprocess"),
            ("preprocess_bwd", "preprocess_bwd_kernel", "K9+K10 backward preprocess")]
 
 
-def model_bytes(P, V, M, F, npix, T, R, nvis, inc, chunks, nblk):
+def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk):
     """HBM bytes ONE launch of each kernel has to move in THIS dataflow, every array once: P Gaussians, V views
     per launch (Pv = V P virtual Gaussians), nvis = sum over the views of Gaussians with radii > 0, R = (Gaussian, tile)
-    instances, inc = (8x8 block, Gaussian) incidences the forward's fills kept, chunks = their 64-survivor chunks (the unit
-    of the forward -> backward state: 3 + F partial sums, T_end, T_mid, last_pos per pixel), npix pixels, T tiles, nblk =
-    preprocess workgroups.  Nothing is charged per (pixel, Gaussian) pair or per instance for the gradient sums: they are
+    instances, inc = (8x8 block, Gaussian) incidences of the chunks some pixel visited, pixel_chunks = (pixel, 64-survivor chunk)
+    pairs visited (the unit of the forward -> backward state: 3 + F partial sums, T_end, T_mid, last_pos per pixel and
+    chunk), npix pixels, T tiles, nblk = preprocess workgroups.  Nothing is charged per (pixel, Gaussian) pair or per instance for the gradient sums: they are
     reduced in registers / LDS and leave as one atomic row per (block, Gaussian), which the L2 merges -- one write-back per
     visible Gaussian.  These are lower bounds of what the kernel must move, so bytes / time <= the HBM roof."""
     Pv = V * P
     rec = 32 + 12 + 4 * F                      # packed record + rgb + feature row of one visible Gaussian
-    state = chunks * 64 * 4 * (3 + F + 3)      # per chunk: partial sums, T_end, T_mid, last_pos
+    state = pixel_chunks * 4 * (3 + F + 3)     # per (pixel, chunk): partial sums, T_end, T_mid, last_pos
     ncol = Pv if M else P                      # dL_dcolors rows: per (view, Gaussian) with SH colours
     zero = 4 * (8 * Pv + 3 * ncol + F * P)     # the backward's accumulator block, zeroed by the forward preprocess
     return {
@@ -587,10 +587,10 @@ def main():
     handle = color_s.grad_fn.num_rendered  # the forward's ForwardHandle (manigaussian_amd/_C.py)
     R = int(handle)
     nvis = int((radii_s > 0).sum().item())
-    inc_, ch_ = ctypes.c_int64(0), ctypes.c_int64(0)
+    inc_, ch_, pc_ = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     _lib.check(_lib.lib().mgs_forward_stats(ctypes.byref(handle.a), launch_views if (deform or V > 1) else 0,
-                                            ctypes.byref(inc_), ctypes.byref(ch_), None), "mgs_forward_stats")
-    incidences, chunks = int(inc_.value), int(ch_.value)
+                                            ctypes.byref(inc_), ctypes.byref(ch_), ctypes.byref(pc_), None), "mgs_forward_stats")
+    incidences, chunks, pixel_chunks = int(inc_.value), int(ch_.value), int(pc_.value)
     del color_s, feat_s, radii_s, handle
 
     # the deformation MLP apart from the rasterizer: forward + backward of this rank's points, hipEvent-timed
@@ -641,7 +641,7 @@ def main():
         npix = W * H * launch_views  # pixels one launch covers
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16) * launch_views
         nblk = launch_views * ((P + 1023) // 1024)
-        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, chunks, nblk)
+        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk)
         so_hash = lib_hash()
         cfiles = counter_files(args.config, launch_views if not deform else 1) if not deform else \
             [f"r04_sq_counters_{args.config}.json"]
@@ -732,7 +732,7 @@ def main():
                        "renders_per_step_per_gpu": renders, "renders_per_step_total": renders_total,
                        "render_launch_views": launch_views, "num_rendered_R": int(R), "R_over_P": R / (P * launch_views),
                        "visible_gaussians_per_launch": nvis, "block_gaussian_incidences_per_launch": incidences,
-                       "chunks_per_launch": chunks,
+                       "chunks_per_launch": chunks, "pixel_chunks_per_launch": pixel_chunks,
                        "tight_bins": _lib.get_option("tight_bins"), "fast_exp": _lib.get_option("fast_exp"),
                        "deformation": ("DeformationField per timestep: HIP input assembly -> fp32 MLP 70->512x5->7 (torch GEMMs, "
                                        "fused HIP elementwise passes) -> HIP apply; gradients of the MLP parameters (one flat "

@@ -296,12 +296,14 @@ int mgs_profile_num_stages(void);
 const char* mgs_profile_stage_name(int stage);
 int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
 
-/* Diagnostic, BLOCKING (one small device->host copy + a stream synchronise): what the forward that last ran on a's
- * workspaces left for its backward -- *incidences = (8x8 pixel block, Gaussian) pairs its fills kept, *chunks = the
- * 64-survivor chunks they make.  V = 0: a single-view forward, V > 0: a batch of V views.  bench.py prices the render
+/* Diagnostic, BLOCKING (two small device->host copies + a stream synchronise): what the forward that last ran on a's
+ * workspaces left for its backward, in the units that state is kept in -- *incidences = (8x8 pixel block, Gaussian) pairs of
+ * the chunks some pixel of the block visited, *chunks = those 64-survivor chunks, *pixel_chunks = (pixel, chunk) pairs visited
+ * (what the per-chunk state costs).  V = 0: a single-view forward, V > 0: a batch of V views.  bench.py prices the render
  * kernels' HBM traffic with them (the reference's dataflow has no such state: RAST/cuda_rasterizer/backward.cu:399-593
  * walks the tile lists again). */
-int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, mgs_stream_t stream);
+int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, int64_t* pixel_chunks,
+                      mgs_stream_t stream);
 
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */

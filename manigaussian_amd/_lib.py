@@ -105,7 +105,7 @@ _EXPORTS = {
     "mgs_novel_calib_host": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 6 +
                              [c_fp] * 5),
     "mgs_forward_stats": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(ctypes.c_int64),
-                                         ctypes.POINTER(ctypes.c_int64), c_fp]),
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), c_fp]),
     "mgs_debug_read_trace": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bwd": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_selftest": (ctypes.c_int, [c_fp]),

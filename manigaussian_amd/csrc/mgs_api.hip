@@ -837,9 +837,12 @@ int mgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
   return MGS_OK;
 }
 
-// Diagnostic (blocking): what the forward that last ran on these workspaces left behind -- the (8x8 block, Gaussian)
-// incidences its fills found and the 64-survivor chunks they make (the unit of the forward -> backward state).
-int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, mgs_stream_t stream_) {
+// Diagnostic (blocking): what the forward that last ran on these workspaces left behind, in the units its state is kept in:
+//   incidences    (8x8 block, Gaussian) pairs of the chunks some pixel of the block visited (the fill may have listed more)
+//   chunks        64-survivor chunks some pixel of their block visited
+//   pixel_chunks  (pixel, chunk) pairs visited: what the per-chunk state (partial sums, T_end, T_mid, last_pos) costs
+int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, int64_t* pixel_chunks,
+                      mgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a || !a->binning || V < 0 || V > MAX_VIEWS) { set_error("forward_stats: bad argument"); return MGS_ERR_INVALID_ARG; }
   const int F = a->include_feature ? a->F : 0;
@@ -848,13 +851,22 @@ int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, in
   if (bs.cap < 0) { set_error("forward_stats: binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
   ChunkView cv;
   (void)carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
-  std::vector<uint2> h((size_t)T * 4);
-  MGS_HIP(hipMemcpyAsync(h.data(), cv.nsurv, h.size() * sizeof(uint2), hipMemcpyDeviceToHost, stream), "forward_stats copy");
+  std::vector<uint2> ns((size_t)T * 4);
+  std::vector<uint32_t> lc((size_t)T * 4 * 64);
+  MGS_HIP(hipMemcpyAsync(ns.data(), cv.nsurv, ns.size() * sizeof(uint2), hipMemcpyDeviceToHost, stream), "forward_stats copy");
+  MGS_HIP(hipMemcpyAsync(lc.data(), cv.last_chunk, lc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "forward_stats copy");
   MGS_HIP(hipStreamSynchronize(stream), "forward_stats sync");
-  int64_t inc = 0, ch = 0;
-  for (const uint2& v : h) { inc += v.x; ch += (v.x + CHUNK - 1) / CHUNK; }
+  int64_t inc = 0, ch = 0, pc = 0;
+  for (size_t b = 0; b < ns.size(); b++) {
+    uint32_t vmax = 0;
+    for (int p = 0; p < 64; p++) { const uint32_t v = lc[b * 64 + p]; pc += v; if (v > vmax) vmax = v; }
+    ch += vmax;
+    const int64_t listed = ns[b].x, visited = (int64_t)vmax * CHUNK;
+    inc += listed < visited ? listed : visited;
+  }
   if (incidences) *incidences = inc;
   if (chunks) *chunks = ch;
+  if (pixel_chunks) *pixel_chunks = pc;
   return MGS_OK;
 }
 

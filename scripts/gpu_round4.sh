@@ -29,7 +29,7 @@ print(c['name'], c['P'], f\"{c['W']}x{c['H']}\", 'renders/gpu', c['renders_per_s
       'kernels_us', {k: round(v['avg_launch_ms'] * 1e3, 1) for k, v in bk.items()}, 'fracs', {k: round(v['frac'], 3) for k, v in bk.items()},
       'mlp', (j.get('roofline_mlp') or {}).get('frac'), 'cpu', (j.get('cpu_baseline') or {}).get('value'))
 "; }
-for W in tests quick exp host bench configs stats stats_dyn pmc variants trace; do
+for W in tests quick exp host pmc bench configs stats stats_dyn variants trace; do
   want "$@" || continue
   case $W in
   tests)
