@@ -305,6 +305,12 @@ int mgs_profile_read(double* total_ms, int32_t* counts, int reset);
 int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, int64_t* chunks, int64_t* pixel_chunks,
                       mgs_stream_t stream);
 
+/* Diagnostic: byte offsets, inside a geom workspace of mgs_geom_bytes(P, M, W, H) bytes, of what the forward preprocess wrote
+ * per Gaussian: depths f32[P]; rec f32x4[2P] = {x, y (pixels), conic.x, conic.y}{conic.z, opacity, hx, hy}; rgb f32[3P];
+ * cov3D f32[6P] (the reference's GeometryState: RAST/cuda_rasterizer/rasterizer_impl.h:30-46).  The parity tests compare
+ * them bit for bit with the reference kernels' values. */
+int mgs_debug_geom_layout(int P, int M, int W, int H, size_t* depths, size_t* rec, size_t* rgb, size_t* cov3D);
+
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */
 int mgs_debug_read_trace(unsigned long long* host, size_t count);

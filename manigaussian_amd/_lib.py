@@ -106,6 +106,7 @@ _EXPORTS = {
                              [c_fp] * 5),
     "mgs_forward_stats": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(ctypes.c_int64),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), c_fp]),
+    "mgs_debug_geom_layout": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.POINTER(c_sz)] * 4),
     "mgs_debug_read_trace": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bwd": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_selftest": (ctypes.c_int, [c_fp]),

@@ -870,6 +870,19 @@ int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, in
   return MGS_OK;
 }
 
+// Diagnostic: byte offsets of the per-Gaussian arrays the forward preprocess leaves in a geom workspace of mgs_geom_bytes(P,
+// M, W, H) bytes (tests compare them bit for bit with the reference's GeometryState).
+int mgs_debug_geom_layout(int P, int M, int W, int H, size_t* depths, size_t* rec, size_t* rgb, size_t* cov3D) {
+  if (P < 0 || W <= 0 || H <= 0) { set_error("geom_layout: bad shape"); return MGS_ERR_INVALID_ARG; }
+  char* const base = reinterpret_cast<char*>(ALIGN);  // (a non-null dummy base: carve_geom yields null pointers for nullptr)
+  const GeomView g = carve_geom(base, P, M, num_tiles(W, H), 1, nullptr);
+  if (depths) *depths = (size_t)(reinterpret_cast<char*>(g.depths) - base);
+  if (rec) *rec = (size_t)(reinterpret_cast<char*>(g.rec) - base);
+  if (rgb) *rgb = (size_t)(reinterpret_cast<char*>(g.rgb) - base);
+  if (cov3D) *cov3D = (size_t)(reinterpret_cast<char*>(g.cov3D) - base);
+  return MGS_OK;
+}
+
 int mgs_profile_num_stages(void) { return ST_COUNT; }
 const char* mgs_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 

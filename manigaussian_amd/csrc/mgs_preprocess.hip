@@ -86,6 +86,69 @@ __device__ __forceinline__ void quat_rows(const float* q, float R[3][3]) {
   R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
 }
 
+// computeCov3D (forward.cu:119-153): Sigma = (S R)^T (S R) with glm's column-major products, the quaternion (r, x, y, z) NOT
+// normalised.  What is computed is the reference's; HOW IT ROUNDS is pinned as well: float products do not associate and
+// a compiler is free to fuse any multiply into a following add (fp-contract), so the same source text rounds one way inside
+// the reference's glm templates and another way in scalar code -- round 4 measured cov3D a few ulps apart on 90 % of the
+// Gaussians, and conics up to 85 ulps apart behind it (scripts/diag/preprocess_bits.py).  Below, every multiply-add is
+// written out the way the reference's kernels evaluate it when built with this toolchain (found by matching their cov3D
+// bit for bit over 92 000 Gaussians, scripts/diag/cov3d_search.py): contraction is switched off for the block and the fused
+// operations are explicit fmaf calls.
+__device__ __forceinline__ void cov3d_from_scale_rotation(const float* __restrict__ q, V3 s, float mod, float* c6) {
+#pragma clang fp contract(off)
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  const float yy = y * y, zz = z * z, rz = r * z, ry = r * y, rx = r * x;
+  // R[i][k] = glm column i, component k (forward.cu:135-139)
+  float R[3][3];
+  R[0][0] = 1.f - 2.f * (yy + zz);
+  R[0][1] = 2.f * __builtin_fmaf(x, y, -rz);
+  R[0][2] = 2.f * __builtin_fmaf(x, z, ry);
+  R[1][0] = 2.f * __builtin_fmaf(r, z, x * y);
+  R[1][1] = 1.f - 2.f * __builtin_fmaf(x, x, zz);
+  R[1][2] = 2.f * __builtin_fmaf(y, z, -rx);
+  R[2][0] = 2.f * __builtin_fmaf(x, z, -ry);
+  R[2][1] = 2.f * __builtin_fmaf(y, z, rx);
+  R[2][2] = 1.f - 2.f * __builtin_fmaf(x, x, yy);
+  const float sc[3] = {mod * s.x, mod * s.y, mod * s.z};
+  float m[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) m[i][k] = sc[k] * R[i][k];
+  // sum of three products p0 + p1 + p2, p_k = m[a][k] m[b][k]: which product is rounded first
+  auto first1 = [&](int a_, int b_) {  // ((p1) + p0 fused) + p2 fused
+    return __builtin_fmaf(m[a_][2], m[b_][2], __builtin_fmaf(m[a_][0], m[b_][0], m[a_][1] * m[b_][1]));
+  };
+  auto first0 = [&](int a_, int b_) {  // ((p0) + p1 fused) + p2 fused
+    return __builtin_fmaf(m[a_][2], m[b_][2], __builtin_fmaf(m[a_][1], m[b_][1], m[a_][0] * m[b_][0]));
+  };
+  c6[0] = first1(0, 0);
+  c6[1] = first0(0, 1);
+  c6[2] = first1(0, 2);
+  c6[3] = first1(1, 1);
+  c6[4] = first1(1, 2);
+  c6[5] = first0(2, 2);
+}
+
+// One row of a 4x4 transform applied to a point, m0 x + m1 y + m2 z + m3, with the rounding of the reference's build pinned
+// the same way (auxiliary.h:58-77 transformPoint4x3 / 4x4: the same source text, yet the compiler fuses another multiply at
+// every use site; scripts/diag/proj_search.py matched the pixel means bit for bit on a camera without structural zeros):
+//   row_view_z  p_view.z of in_frustum = depths[]          ((m0 x fused + m1 y) + m2 z) + m3
+//   row_hom_w   p_hom.w of the projection                  ((m1 y fused + m0 x) + m2 z) + m3
+//   row_hom_xy  p_hom.x, p_hom.y of the projection         (m2 z fused + (m0 x fused + m1 y)) + m3
+__device__ __forceinline__ float row_view_z(float m0, float m1, float m2, float m3, V3 p) {
+#pragma clang fp contract(off)
+  return ((__builtin_fmaf(m0, p.x, m1 * p.y)) + m2 * p.z) + m3;
+}
+__device__ __forceinline__ float row_hom_w(float m0, float m1, float m2, float m3, V3 p) {
+#pragma clang fp contract(off)
+  return ((__builtin_fmaf(m1, p.y, m0 * p.x)) + m2 * p.z) + m3;
+}
+__device__ __forceinline__ float row_hom_xy(float m0, float m1, float m2, float m3, V3 p) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(m2, p.z, __builtin_fmaf(m0, p.x, m1 * p.y)) + m3;
+}
+
 // auxiliary.h:41-44 is written with double literals: evaluate in double, round once.
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
 
@@ -179,37 +242,23 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const float* __restrict__ pm = batch ? a.cam[v].projmatrix : a.projmatrix;
   const float* __restrict__ campos = batch ? a.cam[v].campos : a.campos;
   const V3 p = ld3(a.means3D, gi);
-  const float view_z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+  const float view_z = row_view_z(vm[2], vm[6], vm[10], vm[14], p);
   if (view_z <= 0.2f) {  // auxiliary.h:154 near cull
     if (a.prefiltered) {
       if constexpr (HIST) atomicOr(&s_pref, 1u);  // (handed to the flags word at the end, after the tables are ready)
       else atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
     }
   } else {
-    const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+    const float hw = row_hom_w(pm[3], pm[7], pm[11], pm[15], p);
     const float p_w = 1.0f / (hw + 0.0000001f);
-    const float ndc_x = (pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12]) * p_w;
-    const float ndc_y = (pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13]) * p_w;
+    const float ndc_x = row_hom_xy(pm[0], pm[4], pm[8], pm[12], p) * p_w;
+    const float ndc_y = row_hom_xy(pm[1], pm[5], pm[9], pm[13], p) * p_w;
     float c6[6];
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; i++) c6[i] = a.cov3D_precomp[6 * (size_t)gi + i];
     } else {
-      float R[3][3];
-      quat_rows(a.rotations + 4 * (size_t)gi, R);
-      const V3 s = ld3(a.scales, gi);
-      const float sc[3] = {a.scale_modifier * s.x, a.scale_modifier * s.y, a.scale_modifier * s.z};
-      float m[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) m[i][k] = sc[k] * R[i][k];
-      c6[0] = m[0][0] * m[0][0] + m[0][1] * m[0][1] + m[0][2] * m[0][2];
-      c6[1] = m[0][0] * m[1][0] + m[0][1] * m[1][1] + m[0][2] * m[1][2];
-      c6[2] = m[0][0] * m[2][0] + m[0][1] * m[2][1] + m[0][2] * m[2][2];
-      c6[3] = m[1][0] * m[1][0] + m[1][1] * m[1][1] + m[1][2] * m[1][2];
-      c6[4] = m[1][0] * m[2][0] + m[1][1] * m[2][1] + m[1][2] * m[2][2];
-      c6[5] = m[2][0] * m[2][0] + m[2][1] * m[2][1] + m[2][2] * m[2][2];
+      cov3d_from_scale_rotation(a.rotations + 4 * (size_t)gi, ld3(a.scales, gi), a.scale_modifier, c6);
 #pragma unroll
       for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c6[i];
     }

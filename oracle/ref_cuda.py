@@ -43,6 +43,8 @@ def lib(F: int = 3):
         L.ref_num_feature_channels.restype = ctypes.c_int
         L.ref_forward_backward.restype = ctypes.c_int
         L.ref_forward_backward.argtypes = _INPUTS + [c_fp, c_fp, c_ip] + [c_fp] * 9
+        L.ref_forward_geometry.restype = ctypes.c_int
+        L.ref_forward_geometry.argtypes = _INPUTS + [c_ip] + [c_fp] * 5
         L.ref_bench.restype = ctypes.c_int
         L.ref_bench.argtypes = _INPUTS + [ctypes.c_int, ctypes.c_int] + [c_fp] * 3
         assert int(L.ref_num_feature_channels()) == F
@@ -103,6 +105,41 @@ def forward_backward(means3D, opacities, settings, d_color, d_feat=None, shs=Non
         g["sh"] = np.zeros((P, 0, 3), np.float32)
     t = torch.from_numpy
     return t(color), t(feat), t(radii[:P]), {k: t(v) for k, v in g.items()}, int(R)
+
+
+def forward_geometry(means3D, opacities, settings, shs=None, colors_precomp=None, language_feature=None, scales=None,
+                     rotations=None, cov3D_precomp=None):
+    """What the reference's preprocess (forward.cu:156-257) left in its GeometryState after one forward: dict(radii,
+    means2D [P,2], conic_opacity [P,4], depths [P], rgb [P,3], cov3D [P,6]) as numpy arrays; rows with radii == 0 are
+    unspecified."""
+    F = _width(language_feature)
+    L = lib(F)
+    P = int(means3D.shape[0])
+    M = int(shs.shape[1]) if (shs is not None and shs.numel() != 0) else 0
+    if language_feature is None or language_feature.numel() == 0:
+        language_feature = torch.zeros(P, F)
+    keep = []
+
+    def p(t):
+        a, ptr = _f32(t)
+        keep.append(a)
+        return ptr
+    z = lambda *s: np.zeros(s, np.float32)
+    out = dict(radii=np.zeros((max(P, 1),), np.int32), means2D=z(P, 2), conic_opacity=z(P, 4), depths=z(P), rgb=z(P, 3),
+               cov3D=z(P, 6))
+    o = lambda a: a.ctypes.data_as(c_fp)
+    R = L.ref_forward_geometry(
+        P, int(settings.sh_degree), M, int(settings.image_width), int(settings.image_height), p(settings.bg), p(means3D),
+        p(shs), p(colors_precomp), p(language_feature), p(opacities), p(scales), float(settings.scale_modifier),
+        p(rotations), p(cov3D_precomp), p(settings.viewmatrix), p(settings.projmatrix), p(settings.campos),
+        float(settings.tanfovx), float(settings.tanfovy), int(bool(settings.include_feature)), None, None,
+        out["radii"].ctypes.data_as(c_ip), o(out["means2D"]), o(out["conic_opacity"]), o(out["depths"]), o(out["rgb"]),
+        o(out["cov3D"]))
+    if R < 0:
+        raise RuntimeError(f"reference rasterizer failed ({R})")
+    out["radii"] = out["radii"][:P]
+    out["num_rendered"] = int(R)
+    return out
 
 
 def bench(means3D, opacities, settings, d_color, d_feat, warmup=10, iters=50, shs=None, colors_precomp=None,

@@ -8,6 +8,7 @@
 #include <vector>
 #include "cuda_runtime.h"
 #include "rasterizer.h"
+#include "rasterizer_impl.h"
 #include "config.h"
 
 namespace {
@@ -137,6 +138,31 @@ extern "C" int ref_forward_backward(REF_INPUTS,
     return hipGetLastError() == hipSuccess ? R : -2;
   } catch (const std::exception& e) {
     fprintf(stderr, "ref_forward_backward: %s\n", e.what());
+    return -1;
+  }
+}
+
+// One forward; returns what the reference's preprocess left in its GeometryState (RAST/cuda_rasterizer/rasterizer_impl.h:
+// 30-46): means2D [P,2], conic_opacity [P,4], depths [P], rgb [P,3], cov3D [P,6] (+ radii).  Rows of Gaussians the preprocess
+// returned early for hold whatever the buffer held (compare only where radii > 0).  Returns num_rendered.
+extern "C" int ref_forward_geometry(REF_INPUTS, int* radii, float* means2D, float* conic_opacity, float* depths, float* rgb,
+                                    float* cov3D) {
+  try {
+    Job j;
+    setup(j, REF_INPUT_NAMES);
+    int R = j.forward();
+    hipDeviceSynchronize();
+    if (P > 0) {
+      char* chunk = j.geom.p;
+      CudaRasterizer::GeometryState g = CudaRasterizer::GeometryState::fromChunk(chunk, P);
+      down(radii, j.radii, P);
+      down(means2D, reinterpret_cast<const float*>(g.means2D), 2 * (size_t)P);
+      down(conic_opacity, reinterpret_cast<const float*>(g.conic_opacity), 4 * (size_t)P);
+      down(depths, g.depths, P); down(rgb, g.rgb, 3 * (size_t)P); down(cov3D, g.cov3D, 6 * (size_t)P);
+    }
+    return hipGetLastError() == hipSuccess ? R : -2;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ref_forward_geometry: %s\n", e.what());
     return -1;
   }
 }

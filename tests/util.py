@@ -110,16 +110,19 @@ def grad_errors(g_hip, g_ref):
 #    multiplies per-chunk products into the transmittance entering a chunk (then walks the chunk sequentially): the same
 #    real number, another last bit, and T (1 - alpha) < 1e-4 is a hard decision.  Round 4 measured both
 #    (test_live_reference_exact_exp_*): at 100 000 Gaussians / 128^2 no pixel differs by more than 9.5e-7 under EITHER exp;
-#    at 500 000 / 256^2 (~1e9 pairs) ONE pixel flips its stop decision -- the same pixel, the same 1.16e-4 / 2.03e-4, under
-#    v_exp_f32 AND under ocml expf: the exp is not the cause, the product association is.  (An alpha < 1/255 flip, which
-#    the exp can cause, moves a pixel by up to T |c| / 255: worst seen 2.51e-4, one pixel of one view of the 8-view 100 000
-#    batch.)  Bounds: unmarked pixels 2e-5, a marked pixel REF_FRAGILE_TOL = 5e-4 (2x the worst seen), at most ONE pixel of
-#    an image above the 1e-4 contract; gradients meet the contract (1e-3 of the max) everywhere, marked or not (<= 5.7e-4).
+#    at 500 000 / 256^2 (~1e9 pairs) ONE pixel sat at 1.16e-4 / 2.03e-4 -- the same pixel, the same value, under v_exp_f32
+#    AND under ocml expf, with the exact sequential transmittance chain, with and without the culls: none of the render's
+#    decisions was the cause.  It was the PREPROCESS: cov3D a few ulps from the reference's on 90 % of the Gaussians (another
+#    fused-multiply-add pattern for the same algebra), conics up to 85 ulps behind it.  With the roundings pinned
+#    (test_preprocess_is_bit_identical_to_the_reference_kernels) NO pixel of any live-reference case exceeds the 1e-4
+#    contract (worst: 8.9e-5, one pixel of the 500 000 case; <= 1e-6 at 100 000).  Bounds: unmarked pixels 2e-5, a marked
+#    pixel REF_FRAGILE_TOL = 5e-4 (view batches: an alpha < 1/255 flip moves a pixel by up to T |c| / 255), NO pixel of a
+#    single-view image above the 1e-4 contract; gradients meet the contract (1e-3 of the max) everywhere, marked or not.
 FRAGILE_TOL = 1e-2
 FRAGILE_MAX_FRACTION = 0.02
 REF_FRAGILE_TOL = 5e-4
 REF_FRAGILE_GRAD_TOL = 1e-3
-REF_MAX_PIXELS_ABOVE_CONTRACT = 1
+REF_MAX_PIXELS_ABOVE_CONTRACT = 0
 
 
 def report(tag, **stats):
