@@ -36,12 +36,19 @@ struct ViewCov {
   float a[3], b[3];     // rows of T = W*J that matter: T[0][r], T[1][r] in glm indexing
 };
 
+// computeCov2D (forward.cu:75-114).  The ROUNDING of every multiply-add below is the reference kernels' (hipcc, this
+// toolchain), found by matching their conics bit for bit over 363 000 Gaussians seen through four cameras without structural
+// zeros, both focal signs (scripts/diag/cov2d_ascent.py: a coordinate ascent over the fusion pattern of every sum; it
+// converges to ONE pattern from any start): contraction is off inside these functions, fused operations are explicit.
 __device__ __forceinline__ ViewCov view_cov(V3 mean, const float* __restrict__ vm, float fx, float fy,
                                             float tanx, float tany) {
+#pragma clang fp contract(off)
   ViewCov o;
-  float tx = vm[0] * mean.x + vm[4] * mean.y + vm[8] * mean.z + vm[12];
-  float ty = vm[1] * mean.x + vm[5] * mean.y + vm[9] * mean.z + vm[13];
-  float tz = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
+  // t = transformPoint4x3(mean, viewmatrix) as it rounds INSIDE computeCov2D: ((m1 y fused + m0 x) + m2 z) + m3 for all
+  // three rows (p_view.z of in_frustum, the sort key, fuses m0 x instead: row_view_z)
+  float tx = ((__builtin_fmaf(vm[4], mean.y, vm[0] * mean.x)) + vm[8] * mean.z) + vm[12];
+  float ty = ((__builtin_fmaf(vm[5], mean.y, vm[1] * mean.x)) + vm[9] * mean.z) + vm[13];
+  float tz = ((__builtin_fmaf(vm[6], mean.y, vm[2] * mean.x)) + vm[10] * mean.z) + vm[14];
   const float limx = 1.3f * tanx, limy = 1.3f * tany;
   o.txtz = tx / tz;
   o.tytz = ty / tz;
@@ -50,32 +57,42 @@ __device__ __forceinline__ ViewCov view_cov(V3 mean, const float* __restrict__ v
   o.tx = tx; o.ty = ty; o.tz = tz;
   const float j00 = fx / tz, j02 = -(fx * tx) / (tz * tz);
   const float j11 = fy / tz, j12 = -(fy * ty) / (tz * tz);
-  // T = W * J as glm evaluates it (forward.cu:90-100): every element is the left-to-right sum of three products, J's
-  // zeros included.  The zero terms change no value by themselves, but they decide which product the compiler fuses into an
-  // FMA and which one it rounds first; keeping the reference's expression shape keeps its rounding (a 1-ulp difference in
-  // the 2-D covariance is enough to move ceil(3 sqrt(lambda)) or an alpha across 1/255).
-  const float zero = 0.0f;
+  // T = W * J (forward.cu:90-100): J's zeros drop out; rows 0 and 1 of a fuse the j02 product onto the rounded j00 product,
+  // row 2 adds two rounded products; every row of b fuses the j12 product onto the rounded j11 product
+  o.a[0] = __builtin_fmaf(vm[2], j02, vm[0] * j00);
+  o.a[1] = __builtin_fmaf(vm[6], j02, vm[4] * j00);
+  o.a[2] = vm[8] * j00 + vm[10] * j02;
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    o.a[r] = vm[4 * r + 0] * j00 + vm[4 * r + 1] * zero + vm[4 * r + 2] * j02;
-    o.b[r] = vm[4 * r + 0] * zero + vm[4 * r + 1] * j11 + vm[4 * r + 2] * j12;
-  }
+  for (int r = 0; r < 3; r++) o.b[r] = __builtin_fmaf(vm[4 * r + 2], j12, vm[4 * r + 1] * j11);
   return o;
 }
 
-// cov2D entries (before the +0.3 low-pass) and V*a, V*b for the backward.
+// cov2D entries (before the +0.3 low-pass) and V*a, V*b for the backward: cov = (T^T Vrk^T) T (forward.cu:107); cov[0][1],
+// the entry the reference returns as cov.y, is (V b) . a.  Sums of three products p0 + p1 + p2: `mid` rounds p1 first
+// (fma(p2, fma(p0, round(p1)))), `lead` rounds p0 first.
 __device__ __forceinline__ void cov2d_from(const ViewCov& vc, const float* c6, float& c00, float& c01,
                                            float& c11, float* Va, float* Vb) {
+#pragma clang fp contract(off)
   const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  auto mid = [](float p0, float q0, float p1, float q1, float p2, float q2) {
+    return __builtin_fmaf(p2, q2, __builtin_fmaf(p0, q0, p1 * q1));
+  };
+  auto lead = [](float p0, float q0, float p1, float q1, float p2, float q2) {
+    return __builtin_fmaf(p2, q2, __builtin_fmaf(p1, q1, p0 * q0));
+  };
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    Va[i] = V[i][0] * vc.a[0] + V[i][1] * vc.a[1] + V[i][2] * vc.a[2];
-    Vb[i] = V[i][0] * vc.b[0] + V[i][1] * vc.b[1] + V[i][2] * vc.b[2];
-  }
-  // cov = (T^T Vrk^T) T (forward.cu:107): cov[0][1], the entry the reference returns as cov.y, is (V b) . a
-  c00 = Va[0] * vc.a[0] + Va[1] * vc.a[1] + Va[2] * vc.a[2];
-  c01 = Vb[0] * vc.a[0] + Vb[1] * vc.a[1] + Vb[2] * vc.a[2];
-  c11 = Vb[0] * vc.b[0] + Vb[1] * vc.b[1] + Vb[2] * vc.b[2];
+  for (int i = 0; i < 3; i++) Va[i] = mid(vc.a[0], V[0][i], vc.a[1], V[1][i], vc.a[2], V[2][i]);
+  Vb[0] = lead(vc.b[0], V[0][0], vc.b[1], V[1][0], vc.b[2], V[2][0]);
+  Vb[1] = lead(vc.b[0], V[0][1], vc.b[1], V[1][1], vc.b[2], V[2][1]);
+  Vb[2] = mid(vc.b[0], V[0][2], vc.b[1], V[1][2], vc.b[2], V[2][2]);
+  c00 = mid(Va[0], vc.a[0], Va[1], vc.a[1], Va[2], vc.a[2]);
+  c01 = mid(Vb[0], vc.a[0], Vb[1], vc.a[1], Vb[2], vc.a[2]);
+  c11 = mid(Vb[0], vc.b[0], Vb[1], vc.b[1], Vb[2], vc.b[2]);
+}
+// det of the low-passed 2-D covariance as the reference's build rounds it: c01^2 fused onto the rounded c00 c11
+__device__ __forceinline__ float cov2d_det(float c00, float c01, float c11) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(-c01, c01, c00 * c11);
 }
 
 // Rstd[i][k]: rows as written in forward.cu:135-139 (glm column i), quaternion (r,x,y,z) NOT normalised.
@@ -267,7 +284,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     cov2d_from(vc, c6, c00, c01, c11, Va, Vb);
     c00 += 0.3f;
     c11 += 0.3f;
-    const float det = c00 * c11 - c01 * c01;
+    const float det = cov2d_det(c00, c01, c11);
     if (det != 0.0f) {
       const float det_inv = 1.f / det;
       const float conx = c11 * det_inv, cony = -c01 * det_inv, conz = c00 * det_inv;
