@@ -5,10 +5,24 @@
 
 namespace mgs {
 
+// exp() of the render kernels.  FAST: v_exp_f32 of x log2(e) (two instructions; relative error ~2e-7 |x|).  Otherwise ocml's
+// expf AS THIS TOOLCHAIN EVALUATES IT -- the extended-precision reduction x log2(e) = e + a (|a| <= 1/2), exp2(a), ldexp --
+// without its two range clamps (x < -103.3 -> 0, x > 88.7 -> inf): nine instructions instead of fourteen, bit-identical to
+// expf(x) for -103 < x < 88 (mgs_selftest compares them), and outside that range the callers discard the value anyway (a
+// power > 0 is skipped, forward.cu:349; at x < -103 alpha = opacity * 1e-45 is far below the 1/255 skip threshold either way).
+__device__ __forceinline__ float exp_ocml_unclamped(float x) {
+#pragma clang fp contract(off)
+  const float ph = x * 0x1.715476p+0f;                            // log2(e) rounded to float
+  float pl = __builtin_fmaf(x, 0x1.715476p+0f, -ph);              // the product's rounding error
+  const float e = __builtin_rintf(ph);
+  pl = __builtin_fmaf(x, 0x1.4ae0bep-26f, pl);                    // + x * (log2(e) - float(log2(e)))
+  const float a = (ph - e) + pl;
+  return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
 template <bool FAST>
 __device__ __forceinline__ float exp_(float x) {
   if constexpr (FAST) return __expf(x);
-  else return expf(x);
+  else return exp_ocml_unclamped(x);
 }
 
 // block index -> (tile, sub-block).  Blocks b, b+8, b+16, b+24 (same XCD under the observed

@@ -2,6 +2,7 @@
 // kernel with a KNOWN instruction mix for validating rocprofv3 counter passes (mgs_calibration_kernel).
 #include "mgs_common.h"
 #include "mgs_device.h"
+#include "mgs_render_common.h"
 
 namespace mgs {
 
@@ -59,6 +60,15 @@ __global__ void selftest_kernel(int* result) {
       const float want = (float)(row + 1) * (float)(2 * col + 1) + (float)(row + 101) * (float)(2 * col + 2);
       if (c[i] != want) bad |= 1 << 23;
     }
+  }
+  {  // the render kernels' exact exp (ocml's expf without its range clamps) is expf, bit for bit, over the range that matters:
+     // 64 lanes x 4096 steps sweep x in (-100, 0] on a grid no float pattern favours, plus a few positive values
+    for (int i = 0; i < 4096; i++) {
+      const float x = -((float)(lane * 4096 + i) * 3.8146973e-4f + (float)i * 1.1920929e-7f);
+      if (__float_as_uint(exp_ocml_unclamped(x)) != __float_as_uint(expf(x))) bad |= 1 << 25;
+    }
+    const float xp = (float)lane * 1.37f;
+    if (__float_as_uint(exp_ocml_unclamped(xp)) != __float_as_uint(expf(xp))) bad |= 1 << 25;
   }
   if (bad) atomicOr(result, bad);
 }
