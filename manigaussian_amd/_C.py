@@ -373,6 +373,9 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         a.viewmatrix, a.projmatrix, a.campos = _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
         a.geom, a.geom_bytes, a.img, a.img_bytes = p_geom, gb, p_img, ib
         a.binning, a.binning_bytes = p_bin, bb
+        m_ = st.marks.get(key)
+        if m_ is not None:
+            _lib.auto_seg(a, opts, m_[0], T)
         slot_ptr, tag = st.take_slot()
         # The blocking path leaves binning_capacity at 0: the library then derives the carving from the buffer's BYTE COUNT,
         # which is all a caller of the reference-shaped pair rasterize_gaussians / rasterize_gaussians_backward(R: int,

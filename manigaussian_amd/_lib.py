@@ -181,6 +181,18 @@ def get_option(key: str) -> int:
     return DEFAULT_OPTIONS[key]
 
 
+LONG_LIST = 8192  # instances per tile above which 4096-key segments pay (each key is ranked in half as many segments)
+
+
+def auto_seg(a, opts, mark_R, tiles):
+    """The default segment length (2048) is raised to 4096 for shapes whose tiles hold long lists (BASELINE configs[4]'s shape:
+    14 000 instances per tile = 7 segments of 2048, every key ranked in the six others; sort + merge 115 us instead of 123,
+    profiles/r04_exp_segsort.log): known from the instance count of earlier forwards of the shape.  An explicitly set seg is
+    left alone."""
+    if opts["seg"] == 2048 and mark_R and mark_R > LONG_LIST * tiles:
+        a.opt.seg = 4096
+
+
 def fill_options(a, opts=None):
     """Copy per-call options into a.opt (opts: a dict snapshot, default: DEFAULT_OPTIONS); returns the snapshot."""
     o = DEFAULT_OPTIONS if opts is None else opts

@@ -432,7 +432,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means, cons
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P) return;
   const V3 p = ld3(means, idx);
-  const float z = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+  const float z = row_view_z(vm[2], vm[6], vm[10], vm[14], p);  // p_view.z as in_frustum rounds it (auxiliary.h:139-164)
   present[idx] = (z <= 0.2f) ? 0 : 1;
 }
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,

@@ -112,6 +112,9 @@ class _RasterizeViews(torch.autograd.Function):
                               cov3D_precomp=cov3D_precomp, viewmatrix=None, projmatrix=None, campos=None, geom=geom,
                               binning=binning, img=img)
                 _lib.fill_options(a, opts)
+                m_ = st.marks.get(key)
+                if m_ is not None:
+                    _lib.auto_seg(a, opts, m_[0], V * T1)
                 slot_ptr, tag = st.take_slot()
                 a.binning_capacity, a.chunk_pool, a.status_tag, a.async_forward = cap, pool, tag, 1 if lazy else 0
                 if want and grad_buffer is None:
