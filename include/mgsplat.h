@@ -134,8 +134,10 @@ size_t mgs_backward_scratch_bytes(int P, int M, int F);
 /* Forward, stage 1: preprocess + tile-count scan (K2, K3 of SURVEY.md 2b).
  * Replaces the first half of Rasterizer::forward (RAST/cuda_rasterizer/rasterizer_impl.cu:198-284).
  * Writes radii[P] (int32) and the geom workspace; *num_rendered (HOST int) receives the number of
- * (Gaussian, tile) instances -- this call synchronises the stream once, exactly where the reference
- * does its blocking cudaMemcpy (rasterizer_impl.cu:284). */
+ * (Gaussian, tile) instances of the reference's 3-sigma tile rects -- THE REFERENCE'S INTEGER (rasterizer_impl.cu:280-284),
+ * whatever MgsOptions.tight_bins says (the instances actually binned are fewer under tight_bins = 1; the count is a safe
+ * size for stage 2's workspace) -- this call synchronises the stream once, exactly where the reference does its blocking
+ * cudaMemcpy (rasterizer_impl.cu:284).  (bin_mode 0, the rocPRIM path: the instances binned.) */
 int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
                                      mgs_stream_t stream);
 
@@ -154,7 +156,8 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, c
  *     call sets both words to "pending" before enqueueing.  NULL: the call reads the count back with a blocking copy
  *     instead (same results, slower, no chunk-pool report: a->chunk_pool must then be 0).
  *   a->async_forward == 0: returns once word 0 has arrived (the render may still be running): MGS_OK (images enqueued,
- *     *num_rendered set) or MGS_NEED_CAPACITY (*num_rendered set, geom + radii valid, images NOT rendered: call
+ *     *num_rendered set -- the reference's integer, see mgs_rasterize_forward_preprocess; the status words and
+ *     mgs_forward_result report the instances actually binned, which is what sizes a workspace) or MGS_NEED_CAPACITY (*num_rendered set, geom + radii valid, images NOT rendered: call
  *     mgs_rasterize_forward_render with a binning workspace of at least mgs_binning_bytes(*num_rendered, W, H, F)).
  *     A chunk-pool overflow (only possible with a->chunk_pool != 0) is reported by mgs_forward_result.
  *   a->async_forward == 1: enqueues everything and returns MGS_OK at once with *num_rendered = -1: no host-device

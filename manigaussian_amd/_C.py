@@ -406,9 +406,9 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         else:
             _lib.check(rc, "rasterize_gaussians")
             # a forward that a backward will follow can be repaired there if it overflowed (recover_forward)
+            # (the marks are learned from the device's report -- the instances actually binned --, not from the blocking
+            #  call's return value, which is the reference's 3-sigma-rect count)
             pending = _state.Pending(a, 0, slot_ptr, key, captured=capturing, recoverable=want_grad_buffer and not capturing)
-            if R >= 0 and not capturing:
-                st.learn(key, R)
             st.add(pending)  # captured forwards report at every replay: _state.check_status()
         handle = ForwardHandle(a, opts, pending, R, (background, means3D, sh, colors, language_feature, opacity, scales,
                                                      rotations, cov3D_precomp, viewmatrix, projmatrix, campos),

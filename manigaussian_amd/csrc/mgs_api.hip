@@ -266,6 +266,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   }
   p.tile_hist = segsort ? im.tile_hist : nullptr;
   p.blk_base = segsort ? g.blk_base : nullptr;
+  p.ref_count = segsort ? im.ref_count : nullptr;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_STAGE(launch_preprocess_fwd(p, g, radii, stream), "preprocess", a->debug, stream); }
   if (!segsort) {
@@ -279,9 +280,12 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
 static const char* const kHandshakeMsg =
     "the forward preprocess gave up waiting for its zeroed tile tables (a workgroup of the launch did not make progress for "
     "about a second): nothing was binned for this call";
+// *R_ref: the reference's count (instances of the 3-sigma rects) where the preprocess kept it (segment-sort binning), else *R.
 static int read_count_blocking(const GeomView& g, const ImgView& im, int P, bool segsort, hipStream_t stream, uint32_t* R,
-                               uint32_t* fl) {
+                               uint32_t* fl, uint32_t* R_ref) {
   uint32_t host[2] = {0, 0};
+  uint32_t ref = 0;
+  if (segsort) MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
   unsigned long long mark = 0ull;
   if (segsort && im.nonce)
     MGS_HIP(hipMemcpyAsync(&mark, im.ready + 1, sizeof(mark), hipMemcpyDeviceToHost, stream), "hand-shake read-back");
@@ -291,6 +295,7 @@ static int read_count_blocking(const GeomView& g, const ImgView& im, int P, bool
           "flag read-back");
   MGS_HIP(hipStreamSynchronize(stream), "stream sync");
   *R = host[0]; *fl = host[1];
+  if (R_ref) *R_ref = segsort ? ref : host[0];
   if (segsort && im.nonce && mark == im.nonce) { set_error("%s", kHandshakeMsg); return MGS_ERR_HIP; }
   return MGS_OK;
 }
@@ -411,12 +416,12 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   GeomView g; ImgView im; bool segsort;
   rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
   if (rc) return rc;
-  uint32_t R = 0, fl = 0;
-  rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl);
+  uint32_t R = 0, fl = 0, R_ref = 0;
+  rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl, &R_ref);
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R;
+  *num_rendered = (int32_t)R_ref;  // the reference's integer (>= the instances actually binned: a safe size for stage 2)
   return MGS_OK;
 }
 
@@ -469,11 +474,12 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   if (!segsort || !host_status || a->debug) {
     // no device->host status channel: read back (blocking) like the two-call path
     if (a->async_forward) { set_error("async_forward needs host_status, the segment-sort binning and debug == 0"); return MGS_ERR_INVALID_ARG; }
-    rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl);
+    uint32_t R_ref = 0;
+    rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl, &R_ref);
     if (rc) return rc;
     rc = check_prefiltered(fl);
     if (rc) return rc;
-    *num_rendered = (int32_t)R;
+    *num_rendered = (int32_t)R_ref;  // the reference's integer; the workspace has to hold the R instances actually binned
     if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
     // word 1 (chunk-pool report) still comes from the render kernel when there is a status block; word 0 is known here
     // (the rocPRIM binning has no kernel that would report it)
@@ -495,7 +501,12 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R;
+  {  // a blocking call returns the reference's integer (one more 4-byte read-back; the asynchronous path never does this)
+    uint32_t ref = 0;
+    MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
+    MGS_HIP(hipStreamSynchronize(stream), "stream sync");
+    *num_rendered = (int32_t)ref;
+  }
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
 }
 
@@ -554,7 +565,9 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* rad
   const Options o = options_of(a);
   const int T = num_tiles(a->W, a->H);
   const BinShape bs = bin_shape(a, T, F);
-  if (bs.cap < 0 || R > bs.cap) { set_error("backward: binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
+  // (R is the integer the forward handed back -- the reference's 3-sigma-rect count, at least the instances binned -- or -1:
+  //  only R == 0 is acted on here; that the workspace holds the binned lists was the forward's check)
+  if (bs.cap < 0) { set_error("backward: binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
   GeomView g = carve_geom(a->geom, a->P, a->M, T, 1, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   ChunkView cv;
@@ -729,7 +742,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_ptr = reinterpret_cast<float4*>(a->bwd_accum);
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
-  p.tile_hist = im.tile_hist; p.blk_base = g.blk_base;
+  p.tile_hist = im.tile_hist; p.blk_base = g.blk_base; p.ref_count = im.ref_count;
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
   im.nonce = p.nonce;
   { StageTimer t(ST_PREPROCESS, stream);
@@ -751,7 +764,12 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R;
+  {
+    uint32_t ref = 0;
+    MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
+    MGS_HIP(hipStreamSynchronize(stream), "stream sync");
+    *num_rendered = (int32_t)ref;
+  }
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
 }
 
@@ -790,7 +808,7 @@ int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsVie
     return MGS_ERR_WORKSPACE;
   }
   const BinShape bs = bin_shape(a, at.T, F);
-  if (bs.cap < 0 || R > bs.cap) { set_error("backward (views): binning workspace holds %d instances, need %d", bs.cap, R); return MGS_ERR_WORKSPACE; }
+  if (bs.cap < 0) { set_error("backward (views): binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
   const size_t PV = (size_t)a->P * V, P = (size_t)a->P;
   GeomView g = carve_geom(a->geom, (int)PV, a->M, at.T, V, nullptr);
   ImgView im = carve_img(a->img, a->W, at.H, nullptr);

@@ -68,6 +68,7 @@ struct ImgView {
   uint32_t* flags;        // [4]    see FLAG_*
   uint32_t* tile_hist;    // [T]    instances per tile (filled by the forward preprocess)
   uint32_t* seg_base;     // [T+1]  exclusive scan of the tiles' segment counts
+  uint32_t* ref_count;    // [1]    instances of the reference's 3-sigma rects (its num_rendered); a spare word of the zeroed block
   size_t zero_bytes;      // bytes from flags to the end of seg_base
   // Hand-shake word of the forward preprocess (segment-sort binning): workgroup 0 zeroes the block above and then stores
   // the launch's nonce here; every workgroup waits for the nonce before its first atomic on the block; the bin scatter
@@ -148,6 +149,7 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.flags = c.take<uint32_t>(nz);  // flags | hist | seg_base, contiguous
   v.tile_hist = v.flags ? v.flags + 4 : nullptr;
   v.seg_base = v.flags ? v.tile_hist + S : nullptr;
+  v.ref_count = v.flags ? v.seg_base + S + 1 : nullptr;  // (4 + 2S + 1 is odd, nz a multiple of 64: the word exists and is zeroed)
   v.zero_bytes = nz * sizeof(uint32_t);
   v.ready = c.take<unsigned long long>(2);
   v.nonce = 0ull;
@@ -245,6 +247,7 @@ struct FwdPreArgs {
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
   size_t zero_f4;       // ... in float4 units
   int zero_blocks;      // workgroups at the end of the grid that do nothing else (set by launch_preprocess_fwd)
+  uint32_t* ref_count;  // with tile_hist: ImgView::ref_count (inside the zeroed block), or nullptr
   uint32_t* tables;     // with tile_hist: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
   uint32_t tables_words;
   unsigned long long* ready;  // ImgView::ready

@@ -197,8 +197,8 @@ template <bool HIST>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ uint32_t s_hist[];  // [tiles] when HIST: instances per tile
-  __shared__ uint32_t s_total, s_pref, s_fail;
-  if (HIST && threadIdx.x == 0) { s_total = 0; s_pref = 0; s_fail = 0; }
+  __shared__ uint32_t s_total, s_total_ref, s_pref, s_fail;
+  if (HIST && threadIdx.x == 0) { s_total = 0; s_total_ref = 0; s_pref = 0; s_fail = 0; }
   // HIST launches ONE EXTRA workgroup, index 0, that only zeroes the forward's small tables (flags | tile histogram | segment
   // bases) and publishes the launch's nonce; the working workgroups 1 .. n wait for the nonce right before their first atomic
   // on the tables, at the very end of the kernel -- ten microseconds later.  (Workgroups are dispatched in index order, so
@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   }
   int32_t radius_out = 0;
   uint32_t touched = 0;
+  uint32_t touched_ref = 0;  // tiles of the reference's 3-sigma rect (what ITS num_rendered counts, rasterizer_impl.cu:280-284)
   int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
   // thread 0 looks at the hand-shake word NOW (no wait: the value is examined at the end of the kernel, microseconds later,
   // when workgroup 0's store has long arrived -- a second look is only needed if this one came too early)
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       const float px = ndc2pix(ndc_x, a.W), py = ndc2pix(ndc_y, a.H);
       int x0, y0, x1, y1;
       get_rect(px, py, (int)my_radius, a.tiles_x, a.tiles_y, x0, y0, x1, y1);
+      touched_ref = (uint32_t)((x1 - x0) * (y1 - y0));
       if ((x1 - x0) * (y1 - y0) != 0) {
         const float opacity = a.opacities[gi];
         // bbox of {alpha >= 1/255} = {q(d) <= 2 ln(255 o)}: half extents sqrt(tau * cov_xx), sqrt(tau * cov_yy)
@@ -357,6 +359,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     for (int y = ry0; y < ry1; y++)
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     if (touched) atomicAdd(&s_total, touched);
+    if (touched_ref) atomicAdd(&s_total_ref, touched_ref);
     if (threadIdx.x == 0) {  // the tables are zero once workgroup 0 has published this launch's nonce
       // (workgroup 0 is dispatched first and needs ~2 us.  The wait is BOUNDED: if the nonce has not come after about a
       //  second -- workgroup 0 held by a debugger, a device that lost the store -- this workgroup gives up WITHOUT touching
@@ -377,6 +380,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     __syncthreads();
     if (s_fail) return;
     if (threadIdx.x == 0 && s_total) atomicAdd(&g.flags[FLAG_NUM_RENDERED], s_total);
+    if (threadIdx.x == 0 && s_total_ref && a.ref_count) atomicAdd(a.ref_count, s_total_ref);
     if (threadIdx.x == 0 && s_pref) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
     // reserve this workgroup's slots inside every slice it contributes to; the bin scatter (same
     // PRE_BLOCK partition of the Gaussians) reads the offsets back

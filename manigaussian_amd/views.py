@@ -130,8 +130,6 @@ class _RasterizeViews(torch.autograd.Function):
                     continue
                 _lib.check(rc, "rasterize views")
                 pending = _state.Pending(a, V, slot_ptr, key, captured=capturing, recoverable=want and not capturing)
-                if R >= 0 and not capturing:
-                    st.learn(key, R)
                 st.add(pending)
                 handle = _C.ForwardHandle(a, opts, pending, R, (views, language_feature), views=(views, V),
                                           outs=(_C._weak(out_color), _C._weak(out_feat) if inc and F == F_user else None))
