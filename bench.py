@@ -106,6 +106,7 @@ def parse():
                          "parallel.sparse_all_reduce_grads -- one host read of the row count per step")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
+    ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: the rocPRIM binning)")
     ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
                     help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
                          "host-device synchronisation: what graph capture needs); 'safe' is the package default")
@@ -287,6 +288,8 @@ def main():
         _lib.set_option("tight_bins", args.tight_bins)
     if args.fast_exp is not None:
         _lib.set_option("fast_exp", args.fast_exp)
+    if args.bin_mode is not None:
+        _lib.set_option("bin_mode", args.bin_mode)
     # The package default ("safe") never sizes a workspace speculatively; a training loop that wants a step without any
     # host-device synchronisation -- and HIP-graph capture -- opts into "async", as this benchmark does (--forward-mode).
     manigaussian_amd.set_forward_mode(args.forward_mode)
