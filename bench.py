@@ -106,7 +106,7 @@ def parse():
                          "parallel.sparse_all_reduce_grads -- one host read of the row count per step")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
-    ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: the rocPRIM binning)")
+    ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: binning tables in memory)")
     ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
                     help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
                          "host-device synchronisation: what graph capture needs); 'safe' is the package default")

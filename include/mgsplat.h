@@ -57,7 +57,8 @@ typedef struct MgsOptions {
   int32_t tight_bins;   /* 1*: drop (Gaussian, tile) instances whose alpha >= 1/255 footprint misses the tile      */
   int32_t fast_exp;     /* 0*: the reference's exp, bit for bit (ocml expf); 1: v_exp_f32 (rel. error ~2e-7 |x|, -2.4 % time) */
   int32_t exact_cull;   /* 1*: exact ellipse-vs-block test on top of the bounding-box test in the render forward   */
-  int32_t bin_mode;     /* 1*: histogram + scatter + LDS segment sort + rank merge; 0: rocPRIM scan + radix sort   */
+  int32_t bin_mode;     /* 1*: the bin scatter keeps its per-tile tables in LDS (up to 4096 tiles; more: as 0);
+                           0: tables in memory, one atomic per instance -- any tile count.  Same sort + merge after either */
   int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048, 4096: for lists of >> 8192 per tile)  */
   int32_t gm_waves;     /* 16*: waves per workgroup of the render backward (8 or 16)                               */
   int32_t dbg;          /* 0*: diagnostics of the render forward (256: phase timeline, mgs_debug_read_trace)       */
@@ -137,11 +138,12 @@ size_t mgs_backward_scratch_bytes(int P, int M, int F);
  * (Gaussian, tile) instances of the reference's 3-sigma tile rects -- THE REFERENCE'S INTEGER (rasterizer_impl.cu:280-284),
  * whatever MgsOptions.tight_bins says (the instances actually binned are fewer under tight_bins = 1; the count is a safe
  * size for stage 2's workspace) -- this call synchronises the stream once, exactly where the reference does its blocking
- * cudaMemcpy (rasterizer_impl.cu:284).  (bin_mode 0, the rocPRIM path: the instances binned.) */
+ * cudaMemcpy (rasterizer_impl.cu:284). */
 int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int32_t* num_rendered,
                                      mgs_stream_t stream);
 
-/* Forward, stage 2: duplicate-with-keys, radix sort, tile ranges, alpha-composite render (K4-K7).
+/* Forward, stage 2: per-tile depth-ordered instance lists (what duplicate-with-keys + radix sort + tile ranges produce in
+ * the reference; here: key scatter, segment sort, rank merge) and the alpha-composite render (K4-K7).
  * Replaces rasterizer_impl.cu:286-355.  radii: the [P] int32 array stage 1 wrote.  out_color [3,H,W];
  * out_feature [F,H,W] (untouched if !include_feature).  Both are fully written (no pre-zeroing needed). */
 int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
@@ -197,7 +199,8 @@ int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const i
  * campos / tanfov fields are ignored); images are [V,3,H,W] / [V,F,H,W]; radii, dL_dmeans2D, dL_dconic are [V,P,.];
  * dL_dcolors is [V,P,3] with SH colours (colours differ per view) and [P,3] with colors_precomp; every other gradient is
  * per Gaussian, summed over the views on the device.  Workspaces are sized by the mgs_views_*_bytes functions.
- * host_status is required (see mgs_rasterize_forward; async_forward works the same).  Needs V * tiles <= 4096, V <= 16. */
+ * host_status is required (see mgs_rasterize_forward; async_forward works the same).  Needs V <= 16 (any tile count; V * tiles <= 4096 keeps the
+ * binning tables in LDS). */
 typedef struct MgsView {
   float tanfovx, tanfovy;
   const float* viewmatrix;  /* [16] */

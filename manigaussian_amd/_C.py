@@ -337,7 +337,7 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         guess = (cap_worst, pool_worst) if cannot_overflow else st.guess(key)  # worst case: no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and
-                _state.lazy_allowed(cannot_overflow) and opts["bin_mode"] == 1 and T <= 4096)
+                _state.lazy_allowed(cannot_overflow))
         if capturing and not lazy:
             raise RuntimeError("capturing a rasterizer forward into a HIP graph needs the asynchronous path: "
                                "manigaussian_amd.set_forward_mode('async'), then run this shape eagerly (twice) first so that "

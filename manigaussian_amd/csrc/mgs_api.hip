@@ -59,11 +59,10 @@ static bool supported_F(int F) {
 }
 
 // ---- per-stage timing with hipEvents on the caller's stream (mgs_set_option("profile", 1|2)) ----
-enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_BWD_MEMSET, ST_RENDER_BWD,
-             ST_PREPROCESS_BWD, ST_BIN_SCATTER, ST_BIN_SEGSORT, ST_BIN_MERGE, ST_COUNT };
-// (scan / duplicate_with_keys / binning_sort / ranges_gather: the rocPRIM binning; bin_*: the three kernels of the default one)
-static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_with_keys", "binning_sort",
-                                                  "ranges_gather", "render_fwd", "bwd_memset", "render_bwd",
+enum Stage { ST_PREPROCESS = 0, ST_RENDER_FWD, ST_BWD_MEMSET, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_BIN_SCATTER, ST_BIN_SEGSORT,
+             ST_BIN_MERGE, ST_COUNT };
+// (bin_scatter covers the table kernel too when the tables live in memory)
+static const char* const kStageNames[ST_COUNT] = {"preprocess_fwd", "render_fwd", "bwd_memset", "render_bwd",
                                                   "preprocess_bwd", "bin_scatter", "bin_segsort", "bin_merge"};
 struct Profiler {
   std::mutex mu;
@@ -179,8 +178,8 @@ int mgs_get_option(const char* key) {
 }
 
 static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
-// segment-sort binning keeps per-tile tables in LDS; larger tile grids take the rocPRIM path
-static bool segsort_binning(const Options& o, int T) { return o.bin_mode == 1 && T <= LDS_TILES; }
+// the bin scatter keeps its per-tile tables in LDS; larger tile grids (or bin_mode 0) keep them in memory
+static bool lds_tables(const Options& o, int T) { return o.bin_mode == 1 && T <= LDS_TILES; }
 size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), 1, &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
 static size_t binning_bytes_T(int R, int pool, int T, int F) {
@@ -226,9 +225,9 @@ static BinShape bin_shape(const MgsRasterArgs* a, int T, int F) {
   return s;
 }
 
-// Everything of the forward before the instance count is known: zero tables, preprocess (+ rocPRIM scan).
+// Everything of the forward before the instance count is known: (zero tables,) preprocess.
 static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t* radii, hipStream_t stream, GeomView& g,
-                              ImgView& im, bool& segsort) {
+                              ImgView& im, bool& lds) {
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
   if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img ||
       a->img_bytes < mgs_img_bytes(a->W, a->H)) {
@@ -251,10 +250,10 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
-  segsort = segsort_binning(o, p.tiles_x * p.tiles_y);
-  if (!segsort) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");  // (else: the preprocess does it)
+  lds = lds_tables(o, p.tiles_x * p.tiles_y);
+  if (!lds) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");  // (else: the preprocess does it)
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
-  im.nonce = segsort ? p.nonce : 0ull;
+  im.nonce = lds ? p.nonce : 0ull;
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -264,15 +263,11 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
     p.zero_ptr = reinterpret_cast<float4*>(a->bwd_accum);
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
-  p.tile_hist = segsort ? im.tile_hist : nullptr;
-  p.blk_base = segsort ? g.blk_base : nullptr;
-  p.ref_count = segsort ? im.ref_count : nullptr;
+  p.tile_hist = im.tile_hist;
+  p.blk_base = lds ? g.blk_base : nullptr;
+  p.ref_count = im.ref_count;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_STAGE(launch_preprocess_fwd(p, g, radii, stream), "preprocess", a->debug, stream); }
-  if (!segsort) {
-    StageTimer t(ST_SCAN, stream);
-    MGS_STAGE(launch_scan(g, a->P, stream), "tile-count scan", a->debug, stream);
-  }
   return MGS_OK;
 }
 
@@ -280,23 +275,23 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
 static const char* const kHandshakeMsg =
     "the forward preprocess gave up waiting for its zeroed tile tables (a workgroup of the launch did not make progress for "
     "about a second): nothing was binned for this call";
-// *R_ref: the reference's count (instances of the 3-sigma rects) where the preprocess kept it (segment-sort binning), else *R.
-static int read_count_blocking(const GeomView& g, const ImgView& im, int P, bool segsort, hipStream_t stream, uint32_t* R,
-                               uint32_t* fl, uint32_t* R_ref) {
+// *R_ref: the reference's count (instances of the 3-sigma rects).
+static int read_count_blocking(const GeomView& g, const ImgView& im, hipStream_t stream, uint32_t* R, uint32_t* fl,
+                               uint32_t* R_ref) {
   uint32_t host[2] = {0, 0};
   uint32_t ref = 0;
-  if (segsort) MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
+  MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
   unsigned long long mark = 0ull;
-  if (segsort && im.nonce)
+  if (im.nonce)
     MGS_HIP(hipMemcpyAsync(&mark, im.ready + 1, sizeof(mark), hipMemcpyDeviceToHost, stream), "hand-shake read-back");
-  MGS_HIP(hipMemcpyAsync(&host[0], segsort ? g.flags + FLAG_NUM_RENDERED : g.point_offsets + (P - 1), sizeof(uint32_t),
-                         hipMemcpyDeviceToHost, stream), "num_rendered read-back");
+  MGS_HIP(hipMemcpyAsync(&host[0], g.flags + FLAG_NUM_RENDERED, sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
+          "num_rendered read-back");
   MGS_HIP(hipMemcpyAsync(&host[1], g.flags + FLAG_PREFILTERED, sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
           "flag read-back");
   MGS_HIP(hipStreamSynchronize(stream), "stream sync");
   *R = host[0]; *fl = host[1];
-  if (R_ref) *R_ref = segsort ? ref : host[0];
-  if (segsort && im.nonce && mark == im.nonce) { set_error("%s", kHandshakeMsg); return MGS_ERR_HIP; }
+  if (R_ref) *R_ref = ref;
+  if (im.nonce && mark == im.nonce) { set_error("%s", kHandshakeMsg); return MGS_ERR_HIP; }
   return MGS_OK;
 }
 
@@ -348,13 +343,13 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
   return r;
 }
 
-// Binning + render.  R: instance count if the host knows it (the rocPRIM binning needs it), else -1.
+// Binning + render.  R: instance count if the host knows it (checked against the capacity here), else -1.
 // status: where the device reports (see StatusSink), host == nullptr: nowhere.
 static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const int32_t* radii, float* out_color,
                           float* out_feature, StatusSink status, unsigned long long nonce, hipStream_t stream) {
   const int F = a->include_feature ? a->F : 0;
   const int T = num_tiles(a->W, a->H);
-  const bool segsort = segsort_binning(o, T);
+  const bool lds = lds_tables(o, T);
   GeomView g = carve_geom(a->geom, a->P, a->M, T, 1, nullptr);
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
@@ -367,20 +362,11 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   ChunkView cv;
   BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, &cv, nullptr);
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
-  if (segsort) {
-    for (int k = 0; k < 3; k++) {
-      StageTimer t(ST_BIN_SCATTER + k, stream);
-      MGS_STAGE(launch_bin_segsort(k, g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
-                "segment-sort binning", a->debug, stream);
-    }
-  } else {
-    { StageTimer t(ST_DUPLICATE, stream);
-      MGS_STAGE(launch_duplicate(g, b, im, radii, a->P, R, tiles_x, tiles_y, o.tight_bins, stream),
-                "duplicate_with_keys", a->debug, stream); }
-    { StageTimer t(ST_SORT, stream);
-      MGS_STAGE(launch_sort(b, R, tiles_x, tiles_y, stream), "radix sort", a->debug, stream); }
-    { StageTimer t(ST_RANGES, stream);
-      MGS_STAGE(launch_ranges(g, b, im, R, stream), "tile ranges", a->debug, stream); }
+  (void)radii;
+  for (int k = 0; k < 3; k++) {
+    StageTimer t(ST_BIN_SCATTER + k, stream);
+    MGS_STAGE(launch_bin_segsort(k, lds, g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream), "binning", a->debug,
+              stream);
   }
   const RenderArgs r = render_args(a, o, g);
   { StageTimer t(ST_RENDER_FWD, stream);
@@ -413,11 +399,11 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   *num_rendered = 0;
   if (a->P == 0) return MGS_OK;  // rasterize_points.cu:92
   const Options o = options_of(a);
-  GeomView g; ImgView im; bool segsort;
-  rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
+  GeomView g; ImgView im; bool lds;
+  rc = enqueue_preprocess(a, o, radii, stream, g, im, lds);
   if (rc) return rc;
   uint32_t R = 0, fl = 0, R_ref = 0;
-  rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl, &R_ref);
+  rc = read_count_blocking(g, im, stream, &R, &fl, &R_ref);
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
@@ -464,29 +450,26 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
     return rc;
   }
   const Options o = options_of(a);
-  GeomView g; ImgView im; bool segsort;
+  GeomView g; ImgView im; bool lds;
   const int F = a->include_feature ? a->F : 0;
   const BinShape bs = bin_shape(a, num_tiles(a->W, a->H), F);
   if (!a->binning || bs.cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
-  rc = enqueue_preprocess(a, o, radii, stream, g, im, segsort);
+  rc = enqueue_preprocess(a, o, radii, stream, g, im, lds);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
-  if (!segsort || !host_status || a->debug) {
+  if (!host_status || a->debug) {
     // no device->host status channel: read back (blocking) like the two-call path
-    if (a->async_forward) { set_error("async_forward needs host_status, the segment-sort binning and debug == 0"); return MGS_ERR_INVALID_ARG; }
+    if (a->async_forward) { set_error("async_forward needs host_status and debug == 0"); return MGS_ERR_INVALID_ARG; }
     uint32_t R_ref = 0;
-    rc = read_count_blocking(g, im, a->P, segsort, stream, &R, &fl, &R_ref);
+    rc = read_count_blocking(g, im, stream, &R, &fl, &R_ref);
     if (rc) return rc;
     rc = check_prefiltered(fl);
     if (rc) return rc;
     *num_rendered = (int32_t)R_ref;  // the reference's integer; the workspace has to hold the R instances actually binned
     if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
-    // word 1 (chunk-pool report) still comes from the render kernel when there is a status block; word 0 is known here
-    // (the rocPRIM binning has no kernel that would report it)
-    if (host_status) {
+    if (host_status) {  // (debug: both words are reported by the kernels as usual)
       volatile uint64_t* hs = host_status;
-      hs[1] = kStatusPending;
-      hs[0] = ((uint64_t)(a->status_tag & 0xffffu) << 48) | ((uint64_t)(fl & 0xffffu) << 32) | R;
+      hs[0] = kStatusPending; hs[1] = kStatusPending;
     }
     return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, 0ull, stream);
   }
@@ -641,12 +624,7 @@ static int check_views(const MgsRasterArgs* a, int V, const MgsView* views, MgsR
   if (rc) return rc;
   for (int v = 0; v < V; v++)
     if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].campos) { set_error("view %d: NULL matrix", v); return MGS_ERR_INVALID_ARG; }
-  const Atlas at = atlas_of(a->W, a->H, V);
-  if (!segsort_binning(options_of(a), at.T) || a->debug) {
-    set_error("multi-view batches need the segment-sort binning (opt.bin_mode 1), debug 0 and V * tiles <= %d (got %d)",
-              LDS_TILES, at.T);
-    return MGS_ERR_INVALID_ARG;
-  }
+  if (a->debug) { set_error("multi-view batches need debug 0"); return MGS_ERR_INVALID_ARG; }
   return MGS_OK;
 }
 static void fill_cams(ViewCam* cam, const MgsRasterArgs* a, int V, const MgsView* views) {
@@ -742,9 +720,11 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_ptr = reinterpret_cast<float4*>(a->bwd_accum);
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
-  p.tile_hist = im.tile_hist; p.blk_base = g.blk_base; p.ref_count = im.ref_count;
+  const bool lds = lds_tables(o, at.T);
+  if (!lds) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
+  p.tile_hist = im.tile_hist; p.blk_base = lds ? g.blk_base : nullptr; p.ref_count = im.ref_count;
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
-  im.nonce = p.nonce;
+  im.nonce = lds ? p.nonce : 0ull;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;
@@ -752,8 +732,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   const StatusSink status = {host_status, a->status_tag};
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
-    MGS_HIP(launch_bin_segsort(k, g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
-            "segment-sort binning (views)");
+    MGS_HIP(launch_bin_segsort(k, lds, g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
+            "binning (views)");
   }
   const RenderArgs r = views_render_args(a, o, at, g);
   { StageTimer t(ST_RENDER_FWD, stream);

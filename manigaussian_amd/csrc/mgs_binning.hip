@@ -1,148 +1,23 @@
 // mgs_binning.hip -- tile binning (K3-K6): from per-Gaussian tile rects to per-tile, depth-ordered instance lists.
 //
-// Two implementations of the same result contract (per tile: instances ordered by view-depth bits, ties by
-// Gaussian index -- what the reference's stable radix sort of (tile<<32 | depth) keys yields,
-// RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320):
-//   bin_mode 1 (default)  tile histogram (built by the forward preprocess) -> LDS-aggregated scatter of
-//                         (depth|id) keys into per-tile slices -> bitonic sort of <= SEG-entry segments in LDS
-//                         -> rank merge across a tile's segments + emission.  3 launches, no library calls.
-//                         Keys (depth bits, id) are unique, so the order is deterministic and equals the
-//                         stable sort's order.
-//   bin_mode 0 (rocPRIM)  scan + duplicate + rocPRIM SortPairs + ranges: 20+ launches at R~300k (rocPRIM picks a merge
-//                         sort there).  The path for images with more than LDS_TILES tiles, and an A/B reference.
+// Result contract (per tile: instances ordered by view-depth bits, ties by Gaussian index -- what the reference's stable
+// radix sort of (tile<<32 | depth) keys yields, RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320), reached another
+// way: tile histogram (built by the forward preprocess) -> scatter of (depth|id) keys into per-tile slices -> bitonic sort
+// of <= SEG-entry segments in LDS -> rank merge across a tile's segments + emission.  Keys (depth bits, id) are unique, so
+// the order is deterministic and equals the stable sort's order.  No library calls.
 //
-// Follows RAST/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320 for WHAT is produced (64-bit keys
-// tile<<32 | depth bits, stable order, per-tile [start,end) ranges).  The scan and the radix sort come
-// from rocPRIM through hipCUB exactly as the reference takes them from CUB.
-#include <hipcub/hipcub.hpp>
-
+// The scatter has two forms (the sort and the merge are shared):
+//   LDS tables (bin_mode 1 and T <= LDS_TILES tiles)  the preprocess reserved every workgroup's part of every slice; the
+//                         scatter keeps slice starts, reservations and cursors in LDS.  3 launches.
+//   tables in memory (any tile count; bin_mode 0)     the preprocess counted instances per tile with plain atomics; one
+//                         workgroup scans the histogram into ranges + the segment table, the scatter takes slots with one
+//                         atomic per instance on per-tile cursors.  4 launches.
 #include "mgs_common.h"
 #include "mgs_device.h"
 
 namespace mgs {
 
-size_t scan_temp_bytes(int P) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, P);
-  return bytes + 256;
-}
-
-size_t sort_temp_bytes(int R) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                     (uint32_t*)nullptr, R);
-  return bytes + 256;
-}
-
-hipError_t launch_scan(const GeomView& g, int P, hipStream_t s) {
-  if (P <= 0) return hipSuccess;
-  size_t bytes = g.scan_temp_bytes;
-  return hipcub::DeviceScan::InclusiveSum(g.scan_temp, bytes, g.tiles_touched, g.point_offsets, P, s);
-}
-
-__device__ __forceinline__ void get_rect_b(float px, float py, int rad, int gx, int gy, int& x0, int& y0, int& x1,
-                                           int& y1) {
-  x0 = min(gx, max(0, (int)((px - rad) / TILE)));
-  y0 = min(gy, max(0, (int)((py - rad) / TILE)));
-  x1 = min(gx, max(0, (int)((px + rad + TILE - 1) / TILE)));
-  y1 = min(gy, max(0, (int)((py + rad + TILE - 1) / TILE)));
-}
-
-__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const float4* __restrict__ rec,
-                                                                  const float* __restrict__ depths,
-                                                                  const uint32_t* __restrict__ offsets,
-                                                                  const int32_t* __restrict__ radii,
-                                                                  uint64_t* __restrict__ keys,
-                                                                  uint32_t* __restrict__ vals, int gx, int gy,
-                                                                  int tight_bins) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P) return;
-  const int rad = radii[idx];
-  if (rad <= 0) return;
-  uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
-  const uint32_t end = offsets[idx];
-  if (off == end) return;
-  const float4 r0 = rec[2 * (size_t)idx];
-  const float2 p = make_float2(r0.x, r0.y);
-  int x0, y0, x1, y1;
-  get_rect_b(p.x, p.y, rad, gx, gy, x0, y0, x1, y1);
-  if (tight_bins) {
-    const float4 r1 = rec[2 * (size_t)idx + 1];
-    const float2 h = make_float2(r1.z, r1.w);
-    if (h.x < 0.f) return;
-    const int tx0 = (int)ceilf((p.x - h.x - (TILE - 1)) / TILE), tx1 = (int)floorf((p.x + h.x) / TILE) + 1;
-    const int ty0 = (int)ceilf((p.y - h.y - (TILE - 1)) / TILE), ty1 = (int)floorf((p.y + h.y) / TILE) + 1;
-    x0 = max(x0, tx0); x1 = max(x0, min(x1, tx1));
-    y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
-  }
-  const uint32_t dbits = __float_as_uint(depths[idx]);
-  for (int y = y0; y < y1; y++)
-    for (int x = x0; x < x1; x++) {
-      uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
-      key <<= 32;
-      key |= dbits;
-      keys[off] = key;
-      vals[off] = (uint32_t)idx;
-      off++;
-    }
-}
-
-// ranges (rasterizer_impl.cu:116-138)
-__global__ void __launch_bounds__(256) ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= L) return;
-  const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
-  if (idx == 0)
-    ranges[currtile].x = 0;
-  else {
-    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
-    if (currtile != prevtile) {
-      ranges[prevtile].y = (uint32_t)idx;
-      ranges[currtile].x = (uint32_t)idx;
-    }
-  }
-  if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
-}
-
-// rasterizer_impl.cu:35-50
-static uint32_t higher_msb(uint32_t n) {
-  uint32_t msb = sizeof(n) * 4, step = msb;
-  while (step > 1) {
-    step /= 2;
-    if (n >> msb) msb += step; else msb -= step;
-  }
-  if (n >> msb) msb++;
-  return msb;
-}
-
-hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P, int R,
-                            int tiles_x, int tiles_y, int tight_bins, hipStream_t s) {
-  hipError_t e = launch_zero_bytes(im.ranges, sizeof(uint2) * (size_t)tiles_x * tiles_y, s);
-  if (e != hipSuccess) return e;
-  if (R <= 0 || P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.depths,
-                     g.point_offsets, radii, b.keys_unsorted, b.vals_unsorted, tiles_x, tiles_y,
-                     tight_bins);
-  return hipGetLastError();
-}
-
-hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s) {
-  if (R <= 0) return hipSuccess;
-  const int bit = (int)higher_msb((uint32_t)(tiles_x * tiles_y));
-  size_t bytes = b.sort_temp_bytes;
-  return hipcub::DeviceRadixSort::SortPairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list,
-                                            R, 0, 32 + bit, s);
-}
-
-hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im, int R, hipStream_t s) {
-  if (R <= 0) return hipSuccess;
-  (void)g;
-  hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.keys, im.ranges);
-  return hipGetLastError();
-}
-
-
-// ================================ segment-sort binning (bin_mode 1) ===================================
+// ================================ scatter -> segment sort -> rank merge ===================================
 //
 // preprocess (mgs_preprocess.hip)  tile_hist[t] = instances of tile t; blk_base[b][t] = offset reserved by
 //                                  preprocess workgroup b inside tile t's slice; flags[1] = R
@@ -281,6 +156,76 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
       const int t = y * tiles_x + x;
       const uint32_t slot = s_start[t] + s_base[t] + atomicAdd(&s_cnt[t], 1u);
       keys_unsorted[slot] = key;
+    }
+}
+
+// ---- tables in memory: any tile count ----------------------------------------------------------------------
+// One workgroup: exclusive scan of the tile histogram, LDS_TILES tiles at a time -> ranges, seg_base, seg_desc; reports
+// {tag, flags, R} to the host; zeroes the scatter's cursors.  R > capacity: "nothing binned" (the histogram stays: the
+// caller's retry with a larger workspace starts here again).
+__global__ void __launch_bounds__(1024) bin_tables_kernel(int T, uint32_t seg, uint32_t capacity, const uint32_t* __restrict__ flags,
+                                                          uint64_t* host_status, uint32_t status_tag,
+                                                          const uint32_t* __restrict__ tile_hist,
+                                                          uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ seg_base, uint4* __restrict__ seg_desc) {
+  __shared__ uint32_t s_cnt[LDS_TILES], s_start[LDS_TILES], s_seg[LDS_TILES];
+  __shared__ uint32_t tmp[1024];
+  __shared__ uint32_t total;
+  const int tid = threadIdx.x;
+  const uint32_t R = flags[FLAG_NUM_RENDERED];
+  if (tid == 0 && host_status)
+    __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)(flags[FLAG_PREFILTERED] & 1u) << 32) | R,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool over = R > capacity;
+  uint32_t key_carry = 0, seg_carry = 0;
+  for (int t0 = 0; t0 < T; t0 += LDS_TILES) {
+    const int n = min(LDS_TILES, T - t0);
+    for (int i = tid; i < n; i += blockDim.x) {
+      const uint32_t c = over ? 0u : tile_hist[t0 + i];
+      s_cnt[i] = c; s_start[i] = c; s_seg[i] = div_up_u(c, seg);
+      cursor[t0 + i] = 0u;
+    }
+    __syncthreads();
+    block_exclusive_scan(s_start, n, tmp, &total);
+    const uint32_t keys_here = total;
+    __syncthreads();
+    block_exclusive_scan(s_seg, n, tmp, &total);
+    const uint32_t segs_here = total;
+    for (int i = tid; i < n; i += blockDim.x) {
+      const uint32_t L = s_cnt[i], st = key_carry + s_start[i], sb = seg_carry + s_seg[i];
+      const uint32_t ns = div_up_u(L, seg), seglen = ns ? div_up_u(L, ns) : 0u;
+      ranges[t0 + i] = make_uint2(st, st + L);
+      seg_base[t0 + i] = sb;
+      for (uint32_t k = 0; k < ns; k++) seg_desc[sb + k] = make_uint4(st + k * seglen, min(seglen, L - k * seglen), st, L);
+    }
+    key_carry += keys_here; seg_carry += segs_here;
+    __syncthreads();
+  }
+  if (tid == 0) seg_base[T] = seg_carry;
+}
+
+// One thread per (virtual) Gaussian: slot = slice start + one atomic on the tile's cursor (order inside a slice is
+// arbitrary: the sort that follows makes it deterministic).
+__global__ void __launch_bounds__(256) bin_scatter_global_kernel(int n, int tiles_x, uint32_t capacity,
+                                                                 const uint32_t* __restrict__ flags,
+                                                                 const uint2* __restrict__ rect,
+                                                                 const float* __restrict__ depths,
+                                                                 const uint2* __restrict__ ranges,
+                                                                 uint32_t* __restrict__ cursor,
+                                                                 uint64_t* __restrict__ keys_unsorted) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint2 r = rect[idx];
+  const float depth = depths[idx];
+  if (flags[FLAG_NUM_RENDERED] > capacity) return;
+  const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16);
+  const int y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+  if (x1 <= x0 || y1 <= y0) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) {
+      const int t = y * tiles_x + x;
+      keys_unsorted[ranges[t].x + atomicAdd(&cursor[t], 1u)] = key;
     }
 }
 
@@ -601,12 +546,22 @@ static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im,
                        b.seg_desc, b.keys, b.point_list);
 }
 
-hipError_t launch_bin_segsort(int which, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
+hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V,
+                              int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
   const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
+  if (which == 0 && !lds_tables) {
+    hipLaunchKernelGGL(bin_tables_kernel, dim3(1), dim3(1024), 0, s, T, (uint32_t)seg, (uint32_t)capacity, im.flags, status.host,
+                       status.tag, im.tile_hist, im.cursor, im.ranges, im.seg_base, b.seg_desc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = V * Pg;
+    hipLaunchKernelGGL(bin_scatter_global_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, tiles_x, (uint32_t)capacity, im.flags,
+                       g.rect, g.depths, im.ranges, im.cursor, b.keys_unsorted);
+    return hipGetLastError();
+  }
   if (which == 0) {
     // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,

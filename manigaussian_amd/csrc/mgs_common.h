@@ -17,7 +17,7 @@ constexpr int CHUNK = 64;        // survivors per chunk of the render kernels (t
 #define MGS_PRE_BLOCK 1024
 #endif
 constexpr int PRE_BLOCK = MGS_PRE_BLOCK;  // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
-constexpr int LDS_TILES = 4096;  // max tiles whose per-tile tables fit the binning kernels' LDS (else: rocPRIM binning)
+constexpr int LDS_TILES = 4096;  // max tiles whose per-tile tables fit the binning kernels' LDS (else: tables in memory)
 constexpr int SEG_MIN = 512;     // smallest selectable sort segment (sizes the segment table)
 
 // ---- workspace carving (replaces obtain()/fromChunk, RAST rasterizer_impl.h:19-63) -------------
@@ -50,12 +50,8 @@ struct GeomView {
   float* cov3D;             // [6P]
   uint8_t* clamped;         // [P]   bit c set: SH colour channel c was clamped at 0
   uint2* rect;              // [P]   tile rect the Gaussian is binned into: {x0 | x1<<16, y0 | y1<<16} (x1,y1 exclusive)
-  uint32_t* tiles_touched;  // [P]   (rocPRIM binning only)
-  uint32_t* point_offsets;  // [P]   inclusive scan of tiles_touched (rocPRIM binning only)
   uint32_t* flags;          // -> ImgView::flags
   uint32_t* blk_base;       // [preprocess_blocks(P, V)][T]  offset of preprocess workgroup b's instances inside tile t's slice
-  void* scan_temp;
-  size_t scan_temp_bytes;
 };
 
 // flags[] words of the img workspace (zeroed per forward)
@@ -64,12 +60,14 @@ enum { FLAG_PREFILTERED = 0, FLAG_NUM_RENDERED = 1, FLAG_CHUNKS_USED = 2, FLAG_B
 struct ImgView {
   float* final_T;         // [N]
   uint2* ranges;          // [T]
-  // tile-binning state (mgs_binning.hip); flags .. seg_base are one contiguous block zeroed per forward
+  // tile-binning state (mgs_binning.hip); flags .. seg_base are one contiguous block zeroed per forward (LDS tables: by
+  // the preprocess's workgroup 0; tables in memory: by a zero-fill launch)
   uint32_t* flags;        // [4]    see FLAG_*
   uint32_t* tile_hist;    // [T]    instances per tile (filled by the forward preprocess)
   uint32_t* seg_base;     // [T+1]  exclusive scan of the tiles' segment counts
   uint32_t* ref_count;    // [1]    instances of the reference's 3-sigma rects (its num_rendered); a spare word of the zeroed block
   size_t zero_bytes;      // bytes from flags to the end of seg_base
+  uint32_t* cursor;       // [T]    tables in memory only: the scatter's per-tile write cursors (zeroed by the table kernel)
   // Hand-shake word of the forward preprocess (segment-sort binning): workgroup 0 zeroes the block above and then stores
   // the launch's nonce here; every workgroup waits for the nonce before its first atomic on the block; the bin scatter
   // kernel (next in the chain) stores 0 again.  Replaces a separate zero-fill launch per forward.
@@ -78,14 +76,10 @@ struct ImgView {
 };
 
 struct BinView {
-  uint64_t* keys_unsorted;  // [R]  (depth bits << 32 | id), tile-major, unordered inside a tile  (rocPRIM: tile<<32|depth)
-  uint64_t* keys;           // [R]  segment-sorted keys                                            (rocPRIM: sorted keys)
+  uint64_t* keys_unsorted;  // [R]  (depth bits << 32 | id), tile-major, unordered inside a tile
+  uint64_t* keys;           // [R]  segment-sorted keys
   uint32_t* point_list;     // [R]  sorted Gaussian ids
   uint4* seg_desc;          // [R/SEG_MIN + T + 66] segment -> {first key, count, tile slice start, tile slice length}
-  // rocPRIM binning only; ALIASES the render state below (dead before the render forward starts writing it)
-  uint32_t* vals_unsorted;  // [R]
-  void* sort_temp;
-  size_t sort_temp_bytes;
 };
 
 // Per-(8x8 block, chunk of 64 survivors) state the render forward keeps for the backward.  Chunk records live in a POOL:
@@ -107,9 +101,6 @@ struct ChunkView {
   uint2* nsurv;           // [T*4]  {survivors found by the forward (a prefix of the block's full list), first record of round 0}
 };
 
-size_t scan_temp_bytes(int P);
-size_t sort_temp_bytes(int R);
-
 // P: (virtual) Gaussians = V * Pg for a batch of V views; the preprocess and scatter kernels launch V * ceil(Pg / PRE_BLOCK)
 // workgroups (a workgroup never straddles views), and blk_base has one row per launched workgroup.
 inline size_t preprocess_blocks(size_t P, int V) {
@@ -126,12 +117,8 @@ inline GeomView carve_geom(void* p, int P, int M, int T, int V, size_t* total) {
   g.rgb = c.take<float>(3 * Pa);
   g.cov3D = c.take<float>(6 * Pa);
   g.clamped = c.take<uint8_t>(Pa);
-  g.tiles_touched = c.take<uint32_t>(Pa);
-  g.point_offsets = c.take<uint32_t>(Pa);
   g.flags = nullptr;
   g.blk_base = c.take<uint32_t>(preprocess_blocks(Pa, V) * (size_t)(T > 0 && T <= LDS_TILES ? T : 0) + 1);
-  g.scan_temp_bytes = scan_temp_bytes((int)Pa);
-  g.scan_temp = c.take<char>(g.scan_temp_bytes);
   (void)M;
   if (total) *total = c.total();
   return g;
@@ -152,6 +139,7 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.ref_count = v.flags ? v.seg_base + S + 1 : nullptr;  // (4 + 2S + 1 is odd, nz a multiple of 64: the word exists and is zeroed)
   v.zero_bytes = nz * sizeof(uint32_t);
   v.ready = c.take<unsigned long long>(2);
+  v.cursor = c.take<uint32_t>(S);
   v.nonce = 0ull;
   if (total) *total = c.total();
   return v;
@@ -172,8 +160,6 @@ inline BinView carve_binning(void* p, int R, int T, int F, uint32_t pool, ChunkV
   b.keys = c.take<uint64_t>(Ra);
   b.point_list = c.take<uint32_t>(Ra);
   b.seg_desc = c.take<uint4>(Ra / SEG_MIN + (size_t)T + 66);  // (+64: the merge kernel's grid is rounded up to 64 and every workgroup reads its entry)
-  c.off = align_up(c.off);
-  const size_t alias0 = c.off;  // everything below is written by the render forward, i.e. after the binning is done
   ChunkView v;
   v.pool = pool ? pool : chunk_pool_max(Ra, T);
   const size_t items = v.pool;
@@ -188,15 +174,6 @@ inline BinView carve_binning(void* p, int R, int T, int F, uint32_t pool, ChunkV
   v.q = c.take<float>(items * 64);
   v.partial = c.take<float>(items * (size_t)(3 + F) * 64);
   if (cv) *cv = v;
-  // rocPRIM binning scratch aliases the render state (T > LDS_TILES or bin_mode 0); the workspace is at least that large
-  {
-    Carver a(p);
-    a.off = alias0;
-    b.vals_unsorted = a.take<uint32_t>(Ra);
-    b.sort_temp_bytes = sort_temp_bytes((int)Ra);
-    b.sort_temp = a.take<char>(b.sort_temp_bytes);
-    if (a.off > c.off) c.off = a.off;
-  }
   if (total) *total = c.total();
   return b;
 }
@@ -242,13 +219,14 @@ struct FwdPreArgs {
   int V, Pg, Hp;             // P = V * Pg virtual Gaussians, H = view height, tiles_y = tile rows of ONE view
   int use_cam;               // 1: cameras come from cam[] (the multi-view entry points), 0: from the fields below
   ViewCam cam[MAX_VIEWS];
-  uint32_t* tile_hist;  // [T] instance histogram per tile (zeroed by the caller), or nullptr (rocPRIM binning)
-  uint32_t* blk_base;   // [gridDim][T] (with tile_hist)
+  uint32_t* tile_hist;  // [T] instance histogram per tile
+  uint32_t* blk_base;   // [gridDim][T] LDS tables: the workgroups' reservations; nullptr: tables in memory (the caller zeroed
+                        //              the flags | tile_hist | seg_base block; one atomic per instance on tile_hist)
   float4* zero_ptr;     // optional: block the kernel zeroes on the side (the later backward's accumulators)
   size_t zero_f4;       // ... in float4 units
   int zero_blocks;      // workgroups at the end of the grid that do nothing else (set by launch_preprocess_fwd)
-  uint32_t* ref_count;  // with tile_hist: ImgView::ref_count (inside the zeroed block), or nullptr
-  uint32_t* tables;     // with tile_hist: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
+  uint32_t* ref_count;  // ImgView::ref_count (inside the zeroed block)
+  uint32_t* tables;     // LDS tables: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
   uint32_t tables_words;
   unsigned long long* ready;  // ImgView::ready
   unsigned long long nonce;   // this launch's (non-zero) nonce
@@ -258,22 +236,19 @@ struct FwdPreArgs {
   const float *viewmatrix, *projmatrix, *campos;
 };
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s);
-hipError_t launch_scan(const GeomView& g, int P, hipStream_t s);
 hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
 // Status the device reports to the host (pinned, device-mapped memory): word 0 = tag<<48 | flags<<32 | num_rendered, written
 // by the bin scatter kernel as soon as the preprocess is done; word 1 = tag<<48 | overflow<<32 | chunk records used, written
 // by the last workgroup of the render forward.  tag: 16 bits chosen by the caller (a stale write is recognisable).
 struct StatusSink { uint64_t* host; uint32_t tag; };
-// bin_mode 1: scatter -> segment sort -> rank merge
+// scatter -> segment sort -> rank merge
 unsigned long long next_nonce();  // process-wide counter (never 0) mixed with a per-process random word
 // (three launches, issued one by one so that the stage timers of mgs_api.hip see each kernel: `which` = 0 scatter, 1 segment
 //  sort, 2 rank merge)
-hipError_t launch_bin_segsort(int which, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V, int capacity,
-                              int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
-hipError_t launch_duplicate(const GeomView& g, const BinView& b, const ImgView& im, const int32_t* radii, int P,
-                            int R, int tiles_x, int tiles_y, int tight_bins, hipStream_t s);
-hipError_t launch_sort(const BinView& b, int R, int tiles_x, int tiles_y, hipStream_t s);
-hipError_t launch_ranges(const GeomView& g, const BinView& b, const ImgView& im, int R, hipStream_t s);
+// lds_tables: the scatter keeps the per-tile tables in LDS and uses the preprocess's reservations (T <= LDS_TILES); else a
+// one-workgroup table kernel + a scatter with one atomic per instance on cursors in memory (any tile count).
+hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V,
+                              int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj,
                                uint8_t* present, hipStream_t s);
 

@@ -191,8 +191,9 @@ __device__ __forceinline__ void tight_rect(float px, float py, float hx, float h
   y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
 }
 
-// HIST: also build the per-tile instance histogram (LDS histogram per workgroup, one global atomic per
-// non-empty (workgroup, tile)); the segment-sort binning sizes everything from it.
+// HIST: build the per-tile instance histogram through an LDS histogram per workgroup, one RETURNING global atomic per
+// non-empty (workgroup, tile) -- the workgroup's reservation inside the tile's slice, which the bin scatter reads back.
+// !HIST (tile counts beyond the LDS tables): 256-thread workgroups, one plain atomic per instance.
 template <bool HIST>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a, GeomView g,
                                                                    int32_t* __restrict__ radii) {
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const int gi = (blk - v * bpv) * (int)blockDim.x + (int)threadIdx.x;  // Gaussian
   const int idx = v * a.Pg + gi;                                                    // (virtual) instance owner
   const int Tv = a.tiles_x * a.tiles_y, T = Tv * a.V;
-  if (a.zero_ptr && (!HIST || a.zero_blocks == 0)) {  // (the rocPRIM binning path: on the side, as before)
+  if (a.zero_ptr && (!HIST || a.zero_blocks == 0)) {  // (tables in memory: on the side)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < a.zero_f4; i += (size_t)nwork * blockDim.x)
       a.zero_ptr[i] = z;
@@ -351,10 +352,25 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     }
   }
   radii[idx] = radius_out;
-  g.tiles_touched[idx] = touched;
   if (touched == 0) { rx0 = ry0 = rx1 = ry1 = 0; }
   g.rect[idx] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
   }  // idx < P
+  if constexpr (!HIST) {
+    // Tables in memory (more tiles than the LDS tables hold, or bin_mode 0): one atomic per instance on the tile histogram
+    // -- which the caller zeroed together with the flags --, the counts wave-reduced first.
+    for (int y = ry0; y < ry1; y++)
+      for (int x = rx0; x < rx1; x++) atomicAdd(&a.tile_hist[y * a.tiles_x + x], 1u);
+    uint32_t ts = touched, tr = touched_ref;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      ts += (uint32_t)__shfl_xor((int)ts, d, 64);
+      tr += (uint32_t)__shfl_xor((int)tr, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (ts) atomicAdd(&g.flags[FLAG_NUM_RENDERED], ts);
+      if (tr) atomicAdd(a.ref_count, tr);
+    }
+  }
   if constexpr (HIST) {
     for (int y = ry0; y < ry1; y++)
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
@@ -419,14 +435,14 @@ hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {  // p 4-byt
 
 hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t* radii, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  if (a.tile_hist) {
+  if (a.blk_base) {
     FwdPreArgs b = a;
     // one zeroing workgroup per 16 K float4 (16 stores per thread), at most 128
     b.zero_blocks = b.zero_ptr ? (int)std::min<size_t>(128, (b.zero_f4 + 16383) / 16384) : 0;
     hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK) + 1 + b.zero_blocks),
                        dim3(PRE_BLOCK), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, b, g, radii);
   } else
-    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.Pg + 255) / 256), dim3(256), 0, s, a, g, radii);
+    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(a.V * ((a.Pg + 255) / 256)), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();
 }
 

@@ -85,8 +85,7 @@ class _RasterizeViews(torch.autograd.Function):
                                L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes())
             if cannot_overflow:
                 guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))
-            lazy = (guess is not None and _state.lazy_allowed(cannot_overflow) and opts["bin_mode"] == 1
-                    and not s0.prefiltered)
+            lazy = guess is not None and _state.lazy_allowed(cannot_overflow) and not s0.prefiltered
             if capturing and not lazy:
                 raise RuntimeError("capturing a batched forward into a HIP graph needs the asynchronous path: "
                                    "manigaussian_amd.set_forward_mode('async'), then run this shape eagerly (twice) first so "

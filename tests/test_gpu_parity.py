@@ -141,7 +141,7 @@ CASES = {
     "odd_17x33_f64": dict(P=70, F=64, W=17, H=33),
     "image_512_1024_tiles": dict(P=6000, F=8, W=512, H=512),
     # few Gaussians with huge footprints: many of them own at least one threshold-fragile pixel pair
-    "image_1080p_legacy_binning_fallback": dict(P=3000, F=3, W=1920, H=1080, max_fragile_gaussians=0.5),
+    "image_1080p_binning_tables_in_memory": dict(P=3000, F=3, W=1920, H=1080, max_fragile_gaussians=0.5),
     "other_view": dict(P=4000, F=3, cam_index=3),
 }
 
@@ -154,7 +154,7 @@ def test_parity_with_oracle(name, tight):
 
 _DEFAULTS = dict(gm_waves=16, bin_mode=1, seg=2048, exact_cull=1, fast_exp=0, tight_bins=1)
 VARIANTS = {
-    "rocprim_binning": dict(bin_mode=0),
+    "binning_tables_in_memory": dict(bin_mode=0),
     "segments_512": dict(seg=512), "segments_1024": dict(seg=1024), "segments_4096": dict(seg=4096),
     "backward_8_waves": dict(gm_waves=8),
     "v_exp_f32_bbox_cull": dict(fast_exp=1, exact_cull=0), "v_exp_f32": dict(fast_exp=1),
@@ -296,9 +296,15 @@ def _train_step(d, rast, dC, dF, between=None):
     return c, f, r, grads
 
 
-def test_async_forward_equals_blocking_forward_and_never_synchronises():
-    with _marks_only():
-        _impl_test_async_forward_equals_blocking_forward_and_never_synchronises()
+@pytest.mark.parametrize("bin_mode", [1, 0], ids=["lds_tables", "tables_in_memory"])
+def test_async_forward_equals_blocking_forward_and_never_synchronises(bin_mode):
+    """(bin_mode 0: the table kernel of the in-memory scatter is the one that reports to the host.)"""
+    _lib.set_option("bin_mode", bin_mode)
+    try:
+        with _marks_only():
+            _impl_test_async_forward_equals_blocking_forward_and_never_synchronises()
+    finally:
+        _lib.set_option("bin_mode", _DEFAULTS["bin_mode"])
 
 
 def _impl_test_async_forward_equals_blocking_forward_and_never_synchronises():
@@ -1029,11 +1035,26 @@ def test_sharded_views_on_gpu_equal_sum_of_views():
 
 @pytest.mark.parametrize("case", [dict(P=6000, F=32, V=4, W=128, H=128), dict(P=3000, F=3, V=3, W=72, H=40),
                                   dict(P=2000, F=5, V=2, W=64, H=64, precomp=True),
-                                  dict(P=20000, F=32, V=8, W=128, H=128)],
-                         ids=["f32_4views", "odd_size_3views", "precomp_colors_padded_f5", "f32_8views"])
+                                  dict(P=20000, F=32, V=8, W=128, H=128),
+                                  dict(P=3000, F=3, V=3, W=72, H=40, bin_mode=0),
+                                  dict(P=2500, F=8, V=5, W=512, H=512)],
+                         ids=["f32_4views", "odd_size_3views", "precomp_colors_padded_f5", "f32_8views",
+                              "binning_tables_in_memory", "5120_tiles_batch_in_memory_vs_single_views_in_lds"])
 def test_view_batch_equals_per_view_calls(case):
     """GaussianRasterizerBatch == V GaussianRasterizer calls: images and radii bit for bit (same kernels, same
-    per-pixel arithmetic and order), per-view means2D gradients equal, parameter gradients = sum over the views."""
+    per-pixel arithmetic and order), per-view means2D gradients equal, parameter gradients = sum over the views.
+    The last two cases take the bin scatter with its tables in memory (forced by bin_mode 0; 5 x 1024 tiles exceed the LDS
+    tables while each single view fits them: both scatter forms must yield the same lists)."""
+    from manigaussian_amd import GaussianRasterizerBatch
+    if "bin_mode" in case:
+        _lib.set_option("bin_mode", case["bin_mode"])
+    try:
+        _view_batch_equals_per_view_calls(case)
+    finally:
+        _lib.set_option("bin_mode", _DEFAULTS["bin_mode"])
+
+
+def _view_batch_equals_per_view_calls(case):
     from manigaussian_amd import GaussianRasterizerBatch
     dev = torch.device("cuda:0")
     P, F, V, W, H = case["P"], case["F"], case["V"], case["W"], case["H"]
@@ -1097,7 +1118,7 @@ class _GuardedTorch:
             assert bool((base[n:] == 0xA5).all()), f"a kernel wrote past a {n}-byte workspace"
 
 
-@pytest.mark.parametrize("P,V,W", [(1100, 4, 128), (1025, 16, 128), (20000, 8, 128), (2049, 3, 64)])
+@pytest.mark.parametrize("P,V,W", [(1100, 4, 128), (1025, 16, 128), (20000, 8, 128), (2049, 3, 64), (1100, 5, 512)])
 def test_view_batch_workspaces_are_not_overrun(P, V, W, monkeypatch):
     """Gaussian counts that are not a multiple of the preprocess workgroup (1024) with V > 1: the per-(workgroup, tile) table
     has one row per LAUNCHED workgroup, V * ceil(P / 1024), not ceil(V * P / 1024) (round-2 advisor finding: 2-60 KB were
