@@ -197,7 +197,7 @@ struct Options {
   int tight_bins = 1;      // 1: drop (Gaussian,tile) instances whose alpha>=1/255 footprint misses the tile
   int fast_exp = 0;        // 0: ocml's expf, bit for bit (exp_ocml_unclamped), 1: v_exp_f32 of x log2(e) (rel. error ~2e-7 |x|)
   int exact_cull = 1;      // exact ellipse-vs-block cull on top of the bbox cull in the render forward
-  int bin_mode = 1;        // 1: histogram + scatter + LDS segment sort + rank merge, 0: rocPRIM scan + radix sort
+  int bin_mode = 1;        // 1: the bin scatter's tables in LDS (up to LDS_TILES tiles), 0: in memory (see mgs_binning.hip)
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
   int gm_waves = 16;       // waves per workgroup of the render backward (8 or 16)
   int dbg = 0;             // see RenderArgs::dbg
