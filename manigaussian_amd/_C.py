@@ -436,6 +436,10 @@ def _settle(handle, radii, dev, count):
     if p is None:
         return count
     if p.rc == _lib.MGS_NEED_CAPACITY and not p.captured:
+        if _state.overflow_policy() == "raise":
+            raise RuntimeError("the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
+                               "the head-room over earlier calls of its shape): its images are incomplete and the step is "
+                               "lost; the next call of the shape gets a larger workspace (overflow policy 'raise')")
         return recover_forward(handle, radii, dev)
     if p.rc not in (_lib.MGS_OK, _lib.MGS_PENDING):
         _state.device_state(dev).drain()

@@ -9,6 +9,7 @@ from .views import GaussianRasterizerBatch  # noqa: F401
 from .regressor import gaussian_epilogue  # noqa: F401
 from .voxel import point_latent_pe  # noqa: F401
 from . import camera  # noqa: F401
-from ._state import check_status, forward_mode, set_forward_mode, set_headroom, set_safe_workspace  # noqa: F401
+from ._state import (check_status, forward_mode, overflow_policy, set_forward_mode, set_headroom,  # noqa: F401
+                     set_overflow_policy, set_safe_workspace)
 
 __version__ = "0.1.0"

@@ -61,6 +61,27 @@ def forward_mode() -> str:
     return _MODE
 
 
+# "async" mode only: what the backward does when it learns that ITS forward outgrew the workspace.  "repair": render the
+# forward again on the blocking path into the same output tensors, warn, go on -- the gradients are those of the complete
+# render, but whatever the caller computed from the incomplete images in between (the loss VALUE, its cotangents) is not
+# repaired: the step mixes the two.  "raise": RuntimeError at backward entry; the step is lost, nothing inconsistent is
+# applied.  (The default mode "safe" never gets here.)
+_OVERFLOW = os.environ.get("MGS_OVERFLOW_POLICY", "repair")
+
+
+def set_overflow_policy(policy: str):
+    """"repair" (default) or "raise": see above.  Returns the previous policy."""
+    global _OVERFLOW
+    if policy not in ("repair", "raise"):
+        raise ValueError("overflow policy is 'repair' or 'raise'")
+    old, _OVERFLOW = _OVERFLOW, policy
+    return old
+
+
+def overflow_policy() -> str:
+    return _OVERFLOW
+
+
 def lazy_allowed(cannot_overflow: bool) -> bool:
     """May a forward be enqueued without waiting for its instance count?  "async": always (marks permitting); "safe": only
     with a workspace that cannot overflow; "blocking": never."""
@@ -240,7 +261,7 @@ class DeviceState:
                     f"chunk pool of {p.pool} records")
             msg = ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
                    f"({what}): the images of THAT call were incomplete.  The marks are raised")
-            if p.recovered or (p.recoverable and not p.backward_enqueued and not p.captured):
+            if p.recovered or (_OVERFLOW == "repair" and p.recoverable and not p.backward_enqueued and not p.captured):
                 # its backward re-renders first (manigaussian_amd._C.recover_forward): the gradients come from a complete
                 # forward; only what the caller computed from the incomplete images in between cannot be repaired
                 if not p.recovered:
@@ -250,6 +271,10 @@ class DeviceState:
                               "manigaussian_amd.set_forward_mode('safe') (the default) or a larger set_headroom().", RuntimeWarning,
                               stacklevel=4)
                 return None
+            if p.recoverable and not p.backward_enqueued and not p.captured:  # (overflow policy "raise")
+                p.recovered = True  # its backward, if it still comes, raises too (manigaussian_amd._C._settle)
+                return (msg + "; the step is lost (overflow policy 'raise'): re-run it, or use "
+                        "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.")
             return (msg + " and its gradients were computed on the incomplete state; re-run the step, or use "
                     "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.")
         return f"rasterizer forward failed: {_lib.last_error()} (code {rc})"

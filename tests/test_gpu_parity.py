@@ -420,6 +420,48 @@ def _impl_test_async_overflow_is_reported_loudly_and_recovers():
         assert st.marks[key][0] >= good[0] and st.marks[key][1] is not None and st.marks[key][1] >= good[1]
 
 
+def test_async_overflow_policy_raise_loses_the_step_instead_of_repairing_it():
+    """set_overflow_policy("raise") (round-3 advisor finding: a repaired step still mixes a loss computed from incomplete images
+    with gradients of the complete render): the overflow known at backward entry raises, nothing is repaired, no warning; the
+    marks are raised and the next steps render like the blocking path."""
+    import warnings
+    import manigaussian_amd as mg
+    from manigaussian_amd import _state
+    dev = torch.device("cuda:0")
+    P, F, W = 7000, 3, 128
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
+    dC, dF = dC.to(dev), dF.to(dev)
+    with _forward_mode("blocking"):
+        c0, f0, r0, g0 = _train_step(d, rast, dC, dF)
+        torch.cuda.synchronize()
+    old_policy = mg.set_overflow_policy("raise")
+    try:
+        with _marks_only():
+            for _ in range(3):
+                _train_step(d, rast, dC, dF)
+                mg.check_status(dev)
+            st = _state.device_state(dev)
+            key = (P, W, W, F, 1)
+            good = list(st.marks[key])
+            st.marks[key] = [64, good[1]]
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                with pytest.raises(RuntimeError, match="outgrew"):
+                    _train_step(d, rast, dC, dF, between=torch.cuda.synchronize)
+                    mg.check_status(dev)
+            assert not any("re-renders" in str(x.message) for x in w)
+            torch.cuda.synchronize()
+            assert st.marks[key][0] >= good[0]
+            for _ in range(3):
+                c1, f1, r1, g1 = _train_step(d, rast, dC, dF)
+                mg.check_status(dev)
+            assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+    finally:
+        mg.set_overflow_policy(old_policy)
+
+
 def test_async_overflow_of_a_view_batch_is_repaired_at_backward_entry():
     """The same repair for GaussianRasterizerBatch (mgs_rasterize_forward_views): marks far too small, the report is in before
     the backward -> re-rendered on the blocking path, a warning, images and gradients of the blocking path."""
