@@ -437,7 +437,8 @@ def _settle(handle, radii, dev, count):
         return count
     if p.rc == _lib.MGS_NEED_CAPACITY and not p.captured:
         if _state.overflow_policy() == "raise":
-            raise RuntimeError("the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
+            _state.device_state(dev).drain()  # folds the report into the marks and raises ...
+            raise RuntimeError(               # ... unless an earlier drain already did"the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
                                "the head-room over earlier calls of its shape): its images are incomplete and the step is "
                                "lost; the next call of the shape gets a larger workspace (overflow policy 'raise')")
         return recover_forward(handle, radii, dev)

@@ -374,8 +374,18 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   if constexpr (HIST) {
     for (int y = ry0; y < ry1; y++)
       for (int x = rx0; x < rx1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
-    if (touched) atomicAdd(&s_total, touched);
-    if (touched_ref) atomicAdd(&s_total_ref, touched_ref);
+    {  // the workgroup's instance counts: summed over the wave first (1 024 atomics on one LDS word serialise)
+      uint32_t ts = touched, tr = touched_ref;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        ts += (uint32_t)__shfl_xor((int)ts, d, 64);
+        tr += (uint32_t)__shfl_xor((int)tr, d, 64);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        if (ts) atomicAdd(&s_total, ts);
+        if (tr) atomicAdd(&s_total_ref, tr);
+      }
+    }
     if (threadIdx.x == 0) {  // the tables are zero once workgroup 0 has published this launch's nonce
       // (workgroup 0 is dispatched first and needs ~2 us.  The wait is BOUNDED: if the nonce has not come after about a
       //  second -- workgroup 0 held by a debugger, a device that lost the store -- this workgroup gives up WITHOUT touching
