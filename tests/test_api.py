@@ -166,3 +166,22 @@ def test_split_k_weight_gradient_equals_the_plain_product():
         assert torch.equal(deform._wgrad(g, x), g.t() @ x)
     finally:
         deform._WGRAD_MIN_ROWS = old
+
+
+def test_forward_mode_and_overflow_policy_switches_validate_their_argument():
+    """Host-side switches (no GPU): set_* return the previous value and reject unknown values."""
+    import manigaussian_amd as mg
+    old = mg.set_forward_mode("blocking")
+    try:
+        assert mg.forward_mode() == "blocking" and mg.set_forward_mode("async") == "blocking"
+        with pytest.raises(ValueError):
+            mg.set_forward_mode("lazy")
+    finally:
+        mg.set_forward_mode(old)
+    oldp = mg.set_overflow_policy("raise")
+    try:
+        assert mg.overflow_policy() == "raise" and mg.set_overflow_policy("repair") == "raise"
+        with pytest.raises(ValueError):
+            mg.set_overflow_policy("ignore")
+    finally:
+        mg.set_overflow_policy(oldp)
