@@ -2,7 +2,7 @@
 # downstream reads the variants' garbage reservations)   noret: plain atomics, reservations 0;  noatom: no atomics at all
 export TMPDIR=/tmp; OUT=gpurun_out/preatom; mkdir -p $OUT
 cp manigaussian_amd/libmgsplat.so /tmp/libmgsplat_keep.so
-for v in shipped noret noatom; do
+for v in ${VARIANTS:-shipped noret noatom}; do
   [ $v = shipped ] && cp /tmp/libmgsplat_keep.so manigaussian_amd/libmgsplat.so || cp manigaussian_amd/variants/libmgsplat_$v.so manigaussian_amd/libmgsplat.so
   timeout 150 rocprofv3 --kernel-trace --output-format csv -d $OUT/$v -o t -- python scripts/diag/pre_only.py 40 > $OUT/$v.log 2>&1
   echo "== $v rc=$? $(grep 'P=' $OUT/$v.log | tr '\n' ' ')"
