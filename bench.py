@@ -88,7 +88,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st", "eager-safe", "eager-ctypes"])
     ap.add_argument("--timesteps", type=int, default=None, help="dynamic configs: timesteps per step in total (c4: 4)")
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--F", type=int, default=None)
@@ -111,6 +111,13 @@ def parse():
                     help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
                          "host-device synchronisation: what graph capture needs); 'safe' is the package default")
     ap.add_argument("--strict-roofline", action="store_true", help="exit non-zero if a printed roofline fraction exceeds 1")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="N = 1 only: create an RCCL process group of ONE rank and issue the exact collective call sequence of "
+                         "the N > 1 path (sub-group creation, padded all-gather / reduce-scatter, alternating-bucket async "
+                         "all-reduce) on the device: the RCCL branches run on hardware; what is measured is the calls' cost, "
+                         "not transport")
+    ap.add_argument("--no-reference-kernels", action="store_true", help="skip timing oracle/_ref (the reference's own kernels) "
+                                                                        "beside the cpu_baseline")
     ap.add_argument("--calibrate", action="store_true", help="counter passes: launch the library's known-instruction-mix "
                                                              "kernel a few times first (scripts/sq_counters.py checks it)")
     return ap.parse_args()
@@ -154,6 +161,28 @@ def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds):
                       f"{best * 1e3:.1f} ms, OpenMP {cores} threads"}
 
 
+def reference_kernels(syn, sc, cam, d_color, d_feat, P, F, value):
+    """The REFERENCE's own kernels (oracle/_ref: forward.cu / backward.cu / rasterizer_impl.cu compiled with hipcc for gfx950,
+    rebuilt at this feature width) timed on THIS GPU on the same workload, inputs resident, no PyTorch on their side
+    (oracle/ref_wrapper.cu ref_bench) -- the meaningful same-node comparison beside the CPU port.  Like cpu_baseline this is the
+    checker being timed, never the product; None where the library was not built (it is prebuilt in the development container
+    from /root/reference and travels with the snapshot)."""
+    try:
+        from oracle import ref_cuda
+        if not ref_cuda.available(F):
+            return {"value": None, "note": f"oracle/_ref has no build for {F} feature channels here"}
+        st = types.SimpleNamespace(**syn.camera_settings_kwargs(cam, 1, True))
+        r = ref_cuda.bench(sc["means3D"], sc["opacities"], st, d_color, d_feat, warmup=3, iters=20, shs=sc["shs"],
+                           language_feature=sc["language_feature"], scales=sc["scales"], rotations=sc["rotations"])
+        v = P / r["ms_step"] * 1e3
+        return {"ms_per_step": r["ms_step"], "ms_fwd": r["ms_fwd"], "ms_bwd": r["ms_bwd"], "value": v, "unit": "Gaussians/s",
+                "num_rendered": r["num_rendered"], "this_library_over_reference_kernels": value / v,
+                "what": "the reference's CUDA kernels, unmodified, built by hipcc for gfx950 (oracle/Makefile), 20 fwd+bwd "
+                        "iterations on this GPU, same scene / camera / cotangents"}
+    except Exception as e:  # a baseline must never take the bench line down
+        return {"value": None, "note": f"{type(e).__name__}: {e}"[:200]}
+
+
 def cpu_baseline_dynamic(syn, sc, cam, d_color, d_feat, P, timesteps, renders_total, max_seconds):
     """Dynamic configs on the host cores: the deformation MLP in torch (same module, plain path, fwd + bwd) over a bounded
     SAMPLE of points, scaled linearly to P (the MLP is independent per point), plus Oracle B for one render of the full set;
@@ -193,7 +222,7 @@ def lib_hash():
 def counter_files(cfg_name, views):
     """Committed counter passes for this workload (scripts/gpu_round4.sh writes them), newest round first."""
     suffix = "" if (cfg_name == "c3" and views == 1) else f"_{cfg_name}" + (f"_v{views}" if views > 1 else "")
-    return [f"r{r:02d}_sq_counters{suffix}.json" for r in (4, 3, 2)]
+    return [f"r{r:02d}_sq_counters{suffix}.json" for r in (5, 4, 3, 2)]
 
 
 def committed_counters(kernel_substr, build_id, files):
@@ -284,6 +313,18 @@ def main():
         else:
             dist.init_process_group(args.backend)
     n_gpus = world
+    dry = bool(args.dry_collectives) and world == 1
+    if dry:  # an RCCL group of one rank: every collective of the N > 1 path is issued to the device (parallel._DRY)
+        from manigaussian_amd import parallel as _par
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port_ = s_.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port_))
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
+        _par.set_dry_collectives(True)
+    coll_on = world > 1 or dry
     if args.tight_bins is not None:
         _lib.set_option("tight_bins", args.tight_bins)
     if args.fast_exp is not None:
@@ -349,7 +390,7 @@ def main():
                 p_.mul_(0.05)
         # the MLP's parameter gradients live in ONE flat buffer (the only thing a trainer all-reduces); autograd accumulates
         # into it in place over the timesteps (two alternate when N > 1: a step's asynchronous all-reduce may overlap the next)
-        buckets = [GradBucket(dict(field.named_parameters())) for _ in range(2 if world > 1 else 1)]
+        buckets = [GradBucket(dict(field.named_parameters())) for _ in range(2 if coll_on else 1)]
         bucket_turn = [0]
         plist = list(field.parameters())
         all_settings = [GaussianRasterizationSettings(**syn.camera_settings_kwargs(c, 1, True, device=dev)) for c in cams]
@@ -362,7 +403,7 @@ def main():
                                tgt_c=torch.rand(V_total, 3, H, W, generator=gt)[vs].to(dev),
                                tgt_f=torch.randn(V_total, F, H, W, generator=gt)[vs].to(dev)))
         n_c, n_f = float(renders_total * 3 * H * W), float(renders_total * F * H * W)  # the loss is a mean over ALL renders
-        if plan.group_size > 1 and args.mode == "graph":
+        if (plan.group_size > 1 or plan.group is not None) and args.mode == "graph":
             args.mode = "eager-st"  # collectives inside the step (all-gather / reduce-scatter): the step is enqueued eagerly
 
     last_radii = [None]
@@ -453,7 +494,7 @@ def main():
     pending = {}  # gradient buffer -> work handle of its all-reduce still in flight
 
     def run(stepper, k, collective=True):
-        coll = world > 1 and collective
+        coll = coll_on and collective
         for _ in range(k):
             slot = stepper.next_slot() if coll else None
             if coll and slot is not None:
@@ -483,7 +524,7 @@ def main():
                 h.wait()
         pending.clear()
         torch.cuda.synchronize()
-        if world > 1:
+        if coll_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -510,9 +551,22 @@ def main():
 
     extra_warmup = {}
 
+    from manigaussian_amd import _C as _shim
+
     def measure(mode, steps, warmup, collective=True):
+        # eager-safe: the package's DEFAULT options (forward mode "safe", default autograd threading, compiled binding) --
+        # what an unmodified caller gets; eager-ctypes: the round-4 host path (the ctypes shim) for comparison
+        old_fm = manigaussian_amd.set_forward_mode("safe") if mode == "eager-safe" else None
+        try:
+            with _shim.use_compiled(mode != "eager-ctypes"):
+                return _measure(mode, steps, warmup, collective)
+        finally:
+            if old_fm is not None:
+                manigaussian_amd.set_forward_mode(old_fm)
+
+    def _measure(mode, steps, warmup, collective=True):
         torch.autograd.set_multithreading_enabled(mode != "eager-st")
-        stepper = Graphed(2 if world > 1 else 1) if mode == "graph" else Eager()
+        stepper = Graphed(2 if coll_on else 1) if mode == "graph" else Eager()
         run(stepper, warmup, collective)
         # the W warm-up steps of the driver's short form are 0.8 ms of GPU work after seconds of host-only set-up: the device
         # is still ramping its clocks when the timed region starts.  More of the same steps, untimed, until ~30 ms have passed
@@ -535,7 +589,9 @@ def main():
         for _ in range(3):
             _lib.check(_lib.lib().mgs_calibration_kernel(1000, sink.data_ptr(), None), "calibration")
         torch.cuda.synchronize()
-    all_modes = ("graph", "eager", "eager-st") if not (deform and plan.group_size > 1) else ("eager", "eager-st")
+    all_modes = ("graph", "eager", "eager-st", "eager-safe", "eager-ctypes")
+    if deform and (plan.group_size > 1 or plan.group is not None):
+        all_modes = ("eager", "eager-st", "eager-safe")
     modes = [args.mode] if args.only_mode else [args.mode] + [m for m in all_modes if m != args.mode]
     results, errors, long_runs = {}, {}, {}
     headline_stepper = None
@@ -550,14 +606,40 @@ def main():
             if m == args.mode and m != "graph":
                 raise
             errors[m] = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: mode {m} failed: {errors[m]}", file=sys.stderr)
+    if not results:
+        raise SystemExit(f"bench.py: no mode could be measured: {errors}")
     mode = args.mode if args.mode in results else next(iter(results))
     elapsed, steps = results[mode]
 
+    # SURVEY.md 8d's protocol beside the bracketed mean: a hipEvent pair per step on the work stream, median over <= 100 steps
+    median_ms = None
+    if headline_stepper is not None:
+        torch.autograd.set_multithreading_enabled(mode != "eager-st")
+        n_med = min(max(steps, 20), 100)
+        old_fm = manigaussian_amd.set_forward_mode("safe") if mode == "eager-safe" else None
+        with _shim.use_compiled(mode != "eager-ctypes"):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_med)]
+            sync_all()
+            for e0, e1 in evs:
+                e0.record()
+                run(headline_stepper, 1, collective=True)
+                e1.record()
+            sync_all()
+        if old_fm is not None:
+            manigaussian_amd.set_forward_mode(old_fm)
+        torch.autograd.set_multithreading_enabled(True)
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        median_ms = {"median": ts[len(ts) // 2], "min": ts[0], "p90": ts[int(len(ts) * 0.9)], "steps": n_med,
+                     "what": "hipEvent pair around every step on the work stream (SURVEY.md 8d: median of <= 100); eager "
+                             "modes: the span between the two records holds one step's kernels only when the host runs ahead"}
+        check_status(dev)
+
     exposed_ms, ar_bytes = None, 0
-    if world > 1:
+    if coll_on:
         fa = flat_alias(headline_stepper.last) if headline_stepper is not None else None
         ar_bytes = int(fa.numel() * 4) if fa is not None else int(sum(g.numel() for g in headline_stepper.last) * 4)
-    if world > 1:  # what the collective costs on top of the compute: the same K steps without it
+    if coll_on:  # what the collective costs on top of the compute: the same K steps without it
         el0, k0, _, lr0 = measure(mode, steps, 5, collective=False)
         lr1 = long_runs.get(mode)
         with_ms = (lr1[0] / lr1[1]) if lr1 else elapsed / steps
@@ -585,10 +667,12 @@ def main():
     launch_views = len(groups[0]["views"]) if deform else V
     torch.cuda.synchronize()
     # (a forward of its own whose outputs stay alive: the autograd node keeps the workspaces the statistics are read from)
-    color_s, feat_s, radii_s = deform_group(groups[0]) if deform else render_once(0)
+    with _shim.use_compiled(False):  # (the ctypes shim: its autograd node exposes the forward's handle)
+        color_s, feat_s, radii_s = deform_group(groups[0]) if deform else render_once(0)
     torch.cuda.synchronize()
     handle = color_s.grad_fn.num_rendered  # the forward's ForwardHandle (manigaussian_amd/_C.py)
-    R = int(handle)
+    R = handle.binned()    # (Gaussian, tile) instances the kernels actually move
+    R_reference = int(handle)  # the reference's num_rendered (3-sigma rects), what the call hands back
     nvis = int((radii_s > 0).sum().item())
     inc_, ch_, pc_ = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     _lib.check(_lib.lib().mgs_forward_stats(ctypes.byref(handle.a), launch_views if (deform or V > 1) else 0,
@@ -647,7 +731,7 @@ def main():
         mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk)
         so_hash = lib_hash()
         cfiles = counter_files(args.config, launch_views if not deform else 1) if not deform else \
-            [f"r04_sq_counters_{args.config}.json"]
+            [f"r05_sq_counters_{args.config}.json", f"r04_sq_counters_{args.config}.json"]
         violations = []
 
         def hbm_line(stage, substr, label):
@@ -734,6 +818,7 @@ def main():
                        "views_per_gpu": (renders if deform else V), "timesteps_per_step": cfg.get("timesteps", 1) if deform else 1,
                        "renders_per_step_per_gpu": renders, "renders_per_step_total": renders_total,
                        "render_launch_views": launch_views, "num_rendered_R": int(R), "R_over_P": R / (P * launch_views),
+                       "num_rendered_reference": int(R_reference),
                        "visible_gaussians_per_launch": nvis, "block_gaussian_incidences_per_launch": incidences,
                        "chunks_per_launch": chunks, "pixel_chunks_per_launch": pixel_chunks,
                        "tight_bins": _lib.get_option("tight_bins"), "fast_exp": _lib.get_option("fast_exp"),
@@ -753,10 +838,24 @@ def main():
                                       "1 in-place all-reduce of the per-Gaussian parameter gradients per step, overlapping the "
                                       "next step")},
             "modes_ms_per_step": {m: el / k * 1e3 for m, (el, k) in results.items()}, "mode_errors": errors or None,
-            "distributed": {"backend": args.backend if world > 1 else None,
-                            "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_ids": dev_ids,
+            "modes_note": "graph / eager / eager-st run with --forward-mode (default async: no host-device synchronisation, "
+                          "what capture needs); eager-safe = the package DEFAULTS (forward mode safe: this shape waits for the "
+                          "preprocess's report, default autograd threading): what an unmodified caller gets; eager-ctypes = "
+                          "eager through the round-4 ctypes shim instead of the compiled binding",
+            "host_binding": {"compiled": _shim.compiled() is not None,
+                             "counters": _shim.compiled().counters() if _shim.compiled() is not None else None},
+            "ms_per_step_events": median_ms,
+            "distributed": {"backend": args.backend if coll_on else None,
+                            "world_size_seen": dist.get_world_size() if coll_on else 1, "device_ids": dev_ids,
+                            "dry_collectives": dry,
                             "allreduce_bytes_per_step": ar_bytes,
-                            "allreduce_exposed_ms_per_step": exposed_ms},
+                            "allreduce_exposed_ms_per_step": exposed_ms,
+                            "predicted_ring_allreduce_ms": ({str(n): 2 * (n - 1) / n * ar_bytes / 153e9 * 1e3 for n in (2, 4, 8)}
+                                                            if ar_bytes else None),
+                            "note": ("dry run on ONE device: the RCCL call sequence of the N > 1 path executed (process group "
+                                     "of one rank); exposed time = API + kernel-launch cost of the collectives, no transport. "
+                                     "predicted_ring_allreduce_ms = 2 (N-1)/N x bytes at 153 GB/s per xGMI link direction: a "
+                                     "prediction, never measured by the builder (one GPU)") if dry else None},
             "roofline": roof, "roofline_fwd": roof_fwd, "roofline_by_kernel": by_kernel,
             "roofline_mlp": mlp_block,
             "path_hbm": {"algorithmic_bytes_per_step_per_gpu": path_model,
@@ -772,6 +871,9 @@ def main():
                                  + ("; the deformation MLP's GEMMs are MFMA work: roofline_mlp" if deform else "")},
             "roofline_check": {"all_fractions_le_1": not violations, "violations": violations or None},
             "stages_ms": stages,
+            "stages_note": "hipEvent pairs around each launch (mgs_set_option('profile', 2)): a pair reads ~2 us longer than "
+                           "rocprofv3's kernel duration for the same launch, so their sum exceeds ms_per_step; the committed "
+                           "profiles/r05_rocprofv3_kernel_stats_*.csv carry the kernel durations",
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             if deform:
@@ -780,6 +882,8 @@ def main():
             else:
                 out["cpu_baseline"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if not deform and not args.no_reference_kernels:
+                out["reference_kernels_same_gpu"] = reference_kernels(syn, sc, cam, d_color_h, d_feat_h, P, F, value)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
@@ -787,6 +891,7 @@ def main():
             print("bench.py: roofline fraction above 1: " + "; ".join(violations), file=sys.stderr)
     if world > 1:
         dist.barrier()
+    if coll_on:
         dist.destroy_process_group()
     if args.strict_roofline and rank == 0 and violations:
         raise SystemExit(3)

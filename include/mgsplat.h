@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 6
+#define MGS_ABI_VERSION 7
 
 /* error codes */
 #define MGS_OK 0
@@ -61,7 +61,11 @@ typedef struct MgsOptions {
                            0: tables in memory, one atomic per instance -- any tile count.  Same sort + merge after either */
   int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048, 4096: for lists of >> 8192 per tile)  */
   int32_t gm_waves;     /* 16*: waves per workgroup of the render backward (8 or 16)                               */
-  int32_t dbg;          /* 0*: diagnostics of the render forward (256: phase timeline, mgs_debug_read_trace)       */
+  int32_t dbg;          /* 0*: diagnostics (256: phase timeline of the render forward, mgs_debug_read_trace; 512: test
+                           hook -- the table-zeroing workgroup of the forward preprocess sleeps ~0.3 ms first)          */
+  int32_t table_init;   /* 0*: the forward preprocess launch zeroes its own tile tables (workgroup 0 + a bounded hand-shake:
+                           one launch fewer); 1: a zero-fill launch ahead of it -- no workgroup ever waits for another.
+                           debug = 1 implies 1; a blocking forward whose hand-shake gave up re-runs itself with 1           */
 } MgsOptions;
 void mgs_options_default(MgsOptions* o);  /* fills every field, set = 1 */
 
@@ -152,15 +156,18 @@ int mgs_rasterize_forward_render(const MgsRasterArgs* a, int32_t num_rendered, c
 /* Fused forward: stage 1 + stage 2 in one call with NO mid-call stream synchronisation (the reference blocks on a
  * cudaMemcpy at rasterizer_impl.cu:284; on MI355X that bubble costs more than the binning).  The binning workspace is
  * sized by the CALLER's guess (a->binning_capacity / a->chunk_pool, e.g. the high-water marks of earlier calls).
- *   host_status: 16 bytes of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory), 8-byte aligned, owned
- *     by this call until its result has been read; the device reports {tag, flags, num_rendered} through word 0 as soon as
- *     the preprocess has run and {tag, overflow, chunk records used} through word 1 when the render has finished.  The
- *     call sets both words to "pending" before enqueueing.  NULL: the call reads the count back with a blocking copy
- *     instead (same results, slower, no chunk-pool report: a->chunk_pool must then be 0).
- *   a->async_forward == 0: returns once word 0 has arrived (the render may still be running): MGS_OK (images enqueued,
- *     *num_rendered set -- the reference's integer, see mgs_rasterize_forward_preprocess; the status words and
- *     mgs_forward_result report the instances actually binned, which is what sizes a workspace) or MGS_NEED_CAPACITY (*num_rendered set, geom + radii valid, images NOT rendered: call
- *     mgs_rasterize_forward_render with a binning workspace of at least mgs_binning_bytes(*num_rendered, W, H, F)).
+ *   host_status: 24 bytes (three 64-bit words) of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory),
+ *     8-byte aligned, owned by this call until its result has been read; the device reports {tag, flags, instances binned}
+ *     through word 0 and {tag, the reference's num_rendered} through word 2 as soon as the preprocess has run (word 2 is
+ *     stored first: whoever sees word 0 sees word 2), and {tag, overflow, chunk records used} through word 1 when the render
+ *     has finished.  The call sets the words to "pending" before enqueueing.  NULL: the call reads the counts back with a
+ *     blocking copy instead (same results, slower, no chunk-pool report: a->chunk_pool must then be 0).
+ *   a->async_forward == 0: returns once words 0 and 2 have arrived, i.e. it waits for the PREPROCESS only -- binning and
+ *     render are enqueued and may still be running (ABI v7; v6 synchronised the stream here to read the reference's count):
+ *     MGS_OK (images enqueued, *num_rendered set -- the reference's integer, see mgs_rasterize_forward_preprocess;
+ *     mgs_forward_result reports the instances actually binned, which is what sizes a workspace) or MGS_NEED_CAPACITY
+ *     (*num_rendered set, geom + radii valid, images NOT rendered: call mgs_rasterize_forward_render with a binning
+ *     workspace of at least mgs_binning_bytes(*num_rendered, W, H, F)).
  *     A chunk-pool overflow (only possible with a->chunk_pool != 0) is reported by mgs_forward_result.
  *   a->async_forward == 1: enqueues everything and returns MGS_OK at once with *num_rendered = -1: no host-device
  *     synchronisation at all (the call can be captured into a HIP graph together with its backward).  If the scene outgrew
@@ -175,8 +182,11 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
  * (status_tag, binning_capacity, chunk_pool, binning_bytes and the shape are read).  Returns MGS_PENDING until both words
  * carry this call's tag; then MGS_OK, MGS_NEED_CAPACITY (instances > capacity, or the chunk pool overflowed: the images
  * and any backward of that forward are invalid) or MGS_ERR_INVALID_ARG (prefiltered violation).  *num_rendered and
- * *chunks_used (each optional) receive the counts as soon as their word has arrived (-1 before). */
-int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used);
+ * *chunks_used (each optional) receive the counts as soon as their word has arrived (-1 before); *ref_rendered (optional)
+ * the reference's num_rendered (the 3-sigma-rect instances, RAST/cuda_rasterizer/rasterizer_impl.cu:280-284): the same
+ * integer the blocking entry points return, so every path hands the caller one number. */
+int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used,
+                       int32_t* ref_rendered);
 
 /* Backward (K8-K10).  Replaces Rasterizer::backward (rasterizer_impl.cu:359-463) and the output
  * allocation of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:167-184).  Every non-NULL output
@@ -216,7 +226,7 @@ size_t mgs_views_backward_scratch_bytes(int P, int M, int F, int V);
 int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t* radii, float* out_color,
                                 float* out_feature, int32_t* num_rendered, uint64_t* host_status, mgs_stream_t stream);
 int mgs_forward_result_views(const MgsRasterArgs* a, int32_t V, const uint64_t* host_status, int32_t* num_rendered,
-                             int32_t* chunks_used);  /* mgs_forward_result for a batch of V views */
+                             int32_t* chunks_used, int32_t* ref_rendered);  /* mgs_forward_result for a batch of V views */
 int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t num_rendered,
                                  const int32_t* radii, const float* dL_dout_color, const float* dL_dout_feature,
                                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,

@@ -143,7 +143,9 @@ def _template(P, D, M, F, W, H, tanfovx, tanfovy, scale_modifier, prefiltered, d
 
 class ForwardHandle:
     """What a forward leaves for its backward: the filled MgsRasterArgs (reused, not rebuilt), the per-call options and
-    the pending device report.  int(handle) blocks until the instance count is known (the reference returns it as an int)."""
+    the pending device report.  int(handle) blocks until the instance count is known (the reference returns it as an int):
+    THE REFERENCE'S integer -- the (Gaussian, tile) instances of the 3-sigma rects, rasterizer_impl.cu:280-284 -- on every
+    path (round 4: the asynchronous path handed out the count of instances actually binned); binned() is that other count."""
     __slots__ = ("a", "opts", "pending", "R", "keep", "views", "outs")
 
     def __init__(self, a, opts, pending, R, keep=None, views=None, outs=None):
@@ -153,34 +155,51 @@ class ForwardHandle:
         self.outs = outs    # weak references to (out_color, out_feature): a recovery re-renders into them if they still live
 
     def num_rendered_nowait(self) -> int:
-        """The count if the device has reported it, else -1 (never blocks)."""
+        """The reference's count if the device has reported it, else -1 (never blocks)."""
         if self.R < 0 and self.pending is not None:
             self.pending.poll()
-            self.R = self.pending.num_rendered
+            self.R = self.pending.ref_rendered
         return self.R
+
+    def _wait_report(self):
+        p = self.pending
+        spins = 0
+        while p.num_rendered < 0 and p.poll() == _lib.MGS_PENDING:
+            spins += 1
+            if spins == 100000:  # ~0.1 s of polling: let the stream finish; a count that is still missing never comes
+                torch.cuda.synchronize()
+                if p.num_rendered < 0 and p.poll() == _lib.MGS_PENDING and p.num_rendered < 0:
+                    raise RuntimeError("the rasterizer forward finished without reporting its instance count")
 
     def __int__(self):
         if self.R < 0 and self.pending is not None:
-            spins = 0
-            while self.pending.num_rendered < 0 and self.pending.poll() == _lib.MGS_PENDING:
-                spins += 1
-                if spins == 100000:  # ~0.1 s of polling: let the stream finish; a count that is still missing never comes
-                    torch.cuda.synchronize()
-                    if self.pending.num_rendered < 0 and self.pending.poll() == _lib.MGS_PENDING and \
-                            self.pending.num_rendered < 0:
-                        raise RuntimeError("the rasterizer forward finished without reporting its instance count")
-            self.R = self.pending.num_rendered
+            self._wait_report()
+            self.R = self.pending.ref_rendered
         return self.R
 
     __index__ = __int__
+
+    def binned(self) -> int:
+        """Instances actually binned (<= int(self) under tight_bins): what sizes a workspace and what the kernels move.
+        Blocks like int()."""
+        if self.pending is None:
+            return max(int(self.R), 0)
+        self._wait_report()
+        return self.pending.num_rendered
 
 
 def _capturing() -> bool:
     return torch.cuda.is_current_stream_capturing()
 
 
+def _binned_now(slot_ptr):
+    """The instance count in word 0 of a status slot whose report has arrived."""
+    words, i = _state._WORDS[slot_ptr]
+    return int(words[i]) & 0xffffffff
+
+
 def _launch_forward(L, a, views, radii, out_color, out_feat, slot_ptr, stream):
-    """mgs_rasterize_forward / mgs_rasterize_forward_views -> (rc, num_rendered or -1)."""
+    """mgs_rasterize_forward / mgs_rasterize_forward_views -> (rc, the reference's num_rendered or -1)."""
     nr = ctypes.c_int32(0)
     feat_ptr = out_feat.data_ptr() if (out_feat is not None and a.include_feature) else None
     if views is not None:
@@ -228,8 +247,7 @@ def recover_forward(handle, radii, dev):
     rc, R2 = _launch_forward(L, a, handle.views, radii, out_color, out_feat, slot_ptr, _stream(dev))
     _lib.check(rc, "rasterizer forward (re-run after a workspace overflow)")
     newp = _state.Pending(a, V, slot_ptr, p.key)
-    st.learn(p.key, R2)
-    st.add(newp)
+    st.add(newp)  # (the marks learn the binned count from its report)
     p.recovered = True
     handle.pending, handle.R = newp, R2
     handle.keep = (handle.keep, binning)
@@ -263,6 +281,29 @@ def _grad_offsets(L, P, M, F):
             o += n
         v = _LAYOUTS[k] = (tuple(offs), o)
     return v
+
+
+def compiled():
+    """The compiled autograd binding (csrc/mgs_torch.cpp) or None: manigaussian_amd.rasterizer asks it first."""
+    return _state.ext()
+
+
+class use_compiled:
+    """`with use_compiled(False):` -- route autograd calls through this ctypes shim (diagnostics that need the Python-side
+    ForwardHandle, A/B timing).  No-op when the binding is not built."""
+
+    def __init__(self, on: bool):
+        self.on, self.old = bool(on), None
+
+    def __enter__(self):
+        e = _state.ext()
+        self.old = e.set_enabled(self.on) if e else None
+        return self
+
+    def __exit__(self, *exc):
+        e = _state.ext()
+        if e and self.old is not None:
+            e.set_enabled(self.old)
 
 
 def rasterize_gaussians(background, means3D, colors, language_feature, opacity, scales, rotations, scale_modifier,
@@ -395,14 +436,14 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         rc, R = _launch_forward(L, a, None, radii, out_color, out_feat, slot_ptr, stream)
         pending = None
         binning2 = None
-        if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) first call for this shape, or the scene grew: bin + render again
-            cap = R + R // 4 + 4096
+        if rc == _lib.MGS_NEED_CAPACITY:  # (waiting path) first call for this shape, or the scene grew: bin + render again
+            cap = R + R // 4 + 4096  # (R: the reference's 3-sigma-rect count, at least the instances binned)
             binning2 = torch.empty((L.mgs_binning_bytes2(cap, 0, W, H, F),), **u8)
             a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool = binning2.data_ptr(), binning2.numel(), 0, 0
             rc = L.mgs_rasterize_forward_render(ctypes.byref(a), R, radii.data_ptr(), out_color.data_ptr(), feat_ptr,
                                                 stream)
             _lib.check(rc, "rasterize_gaussians")
-            st.learn(key, R)
+            st.learn(key, _binned_now(slot_ptr))  # the marks hold BINNED counts (advisor r4: not the 3-sigma-rect count)
         else:
             _lib.check(rc, "rasterize_gaussians")
             # a forward that a backward will follow can be repaired there if it overflowed (recover_forward)
@@ -438,7 +479,8 @@ def _settle(handle, radii, dev, count):
     if p.rc == _lib.MGS_NEED_CAPACITY and not p.captured:
         if _state.overflow_policy() == "raise":
             _state.device_state(dev).drain()  # folds the report into the marks and raises ...
-            raise RuntimeError(               # ... unless an earlier drain already did"the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
+            # ... unless an earlier drain already did:
+            raise RuntimeError("the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
                                "the head-room over earlier calls of its shape): its images are incomplete and the step is "
                                "lost; the next call of the shape gets a larger workspace (overflow policy 'raise')")
         return recover_forward(handle, radii, dev)

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -25,7 +25,7 @@ SUPPORTED_F = (3, 4, 8, 16, 32, 64)
 
 class MgsOptions(ctypes.Structure):
     _fields_ = [("set", c_i32), ("tight_bins", c_i32), ("fast_exp", c_i32), ("exact_cull", c_i32), ("bin_mode", c_i32),
-                ("seg", c_i32), ("gm_waves", c_i32), ("dbg", c_i32)]
+                ("seg", c_i32), ("gm_waves", c_i32), ("dbg", c_i32), ("table_init", c_i32)]
 
 
 class MgsRasterArgs(ctypes.Structure):
@@ -65,9 +65,9 @@ _EXPORTS = {
     "mgs_binning_bytes2": (c_sz, [ctypes.c_int] * 5),
     "mgs_chunk_pool_max": (ctypes.c_int, [ctypes.c_int] * 3),
     "mgs_forward_result": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp, ctypes.POINTER(c_i32),
-                                          ctypes.POINTER(c_i32)]),
+                                          ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "mgs_forward_result_views": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, c_fp, ctypes.POINTER(c_i32),
-                                                ctypes.POINTER(c_i32)]),
+                                                ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "mgs_views_binning_bytes2": (c_sz, [ctypes.c_int] * 6),
     "mgs_views_chunk_pool_max": (ctypes.c_int, [ctypes.c_int] * 4),
     "mgs_calibration_kernel": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp]),
@@ -157,7 +157,7 @@ def check(rc: int, what: str):
 
 # Per-call tuning switches (MgsOptions): the C ABI has no process-wide option state; this dict is merely the DEFAULT the
 # Python shim copies into every call's MgsRasterArgs.opt (a forward's values travel to its backward in the autograd ctx).
-DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=1, seg=2048, gm_waves=16, dbg=0)
+DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=1, seg=2048, gm_waves=16, dbg=0, table_init=0)
 OPTIONS_VERSION = [0]  # bumped by set_option: callers that cache a filled MgsOptions key it on this
 
 
@@ -171,8 +171,19 @@ def set_option(key: str, value: int):
             raise RuntimeError("seg must be 512, 1024, 2048 or 4096")
         DEFAULT_OPTIONS[key] = int(value)
         OPTIONS_VERSION[0] += 1
+        push_options()
     else:
         raise RuntimeError(f"unknown option {key}")
+
+
+def push_options():
+    """Hand the per-call defaults to the compiled binding (it fills MgsRasterArgs.opt itself)."""
+    from . import _state
+    e = _state._EXT[0]
+    if e:
+        o = DEFAULT_OPTIONS
+        e.set_options(o["tight_bins"], o["fast_exp"], o["exact_cull"], o["bin_mode"], o["seg"], o["gm_waves"], o["dbg"],
+                      o["table_init"])
 
 
 def get_option(key: str) -> int:
@@ -199,7 +210,7 @@ def fill_options(a, opts=None):
     q = a.opt
     q.set = 1
     q.tight_bins, q.fast_exp, q.exact_cull, q.bin_mode = o["tight_bins"], o["fast_exp"], o["exact_cull"], o["bin_mode"]
-    q.seg, q.gm_waves, q.dbg = o["seg"], o["gm_waves"], o["dbg"]
+    q.seg, q.gm_waves, q.dbg, q.table_init = o["seg"], o["gm_waves"], o["dbg"], o["table_init"]
     return o if opts is not None else dict(o)
 
 

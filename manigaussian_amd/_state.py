@@ -5,8 +5,10 @@ its binning buffer is sized from that count.  Three forward modes (set_forward_m
 
   "safe" (default)  a forward can NEVER hand back incomplete images.  A shape whose worst-case workspace fits the budget
                     (set_safe_workspace, default 1 GB: ManiGaussian's own 16 384-Gaussian shape needs 206 MB) is enqueued
-                    without any host-device synchronisation -- it cannot overflow; every other shape waits for the instance
-                    count like the reference does and sizes its buffer from it (a retry when the scene grew).
+                    without any host-device synchronisation -- it cannot overflow; every other shape enqueues everything
+                    with a workspace sized from the shape's marks and waits for the PREPROCESS's report only (two pinned
+                    words; round 4 waited for the whole render): binning and render are running while the call returns, and
+                    a scene that outgrew the buffer is binned and rendered again with room before the call returns.
   "async" (opt-in)  every shape is enqueued without synchronisation: the workspace is sized from what earlier forwards of the
                     same shape needed (high-water marks + head-room) and the device reports {instances, chunk records used,
                     overflow} through two pinned host words.  What HIP-graph capture and a GPU-bound 0.15 ms step need;
@@ -26,6 +28,7 @@ later call into this module raises RuntimeError (loud, late) after raising the m
 forward of a shape, `debug=True` settings and `set_forward_mode("blocking")` take the blocking path, which cannot overflow.
 """
 import collections
+import collections.abc
 import ctypes
 import os
 import threading
@@ -35,7 +38,49 @@ import torch
 
 from . import _lib
 
-NSLOTS = 1024  # status slots per device (two 64-bit words each); far more than forwards can be in flight
+NSLOTS = 1024  # status slots per device (four 64-bit words each, three used); far more than forwards can be in flight
+SLOT_WORDS = 4
+SLOT_BYTES = 8 * SLOT_WORDS
+
+# ---- the compiled binding (csrc/mgs_torch.cpp -> _mgs_torch.so): owns the marks and the hot autograd path when present --------
+_EXT = [False]  # False: not looked for yet; None: absent / disabled; else the module
+
+
+def ext():
+    """manigaussian_amd._mgs_torch, or None (not built, MGS_NO_COMPILED=1): the ctypes shim then does everything."""
+    e = _EXT[0]
+    if e is False:
+        e = None
+        if not os.environ.get("MGS_NO_COMPILED"):
+            try:
+                _lib.lib()  # the binding links libmgsplat.so: fail with the loader's message, not the linker's
+                from . import _mgs_torch as e
+                if e.ABI_VERSION != _lib.ABI_VERSION:
+                    raise ImportError(f"_mgs_torch ABI {e.ABI_VERSION} != {_lib.ABI_VERSION}")
+            except ImportError as err:
+                warnings.warn(f"manigaussian_amd: the compiled binding is not available ({err}); using the ctypes shim "
+                              "(same kernels, ~3x the host time per call).  Build it with `make -C manigaussian_amd/csrc ext`.",
+                              RuntimeWarning)
+                e = None
+        _EXT[0] = e
+        if e is not None:
+            _push_config()
+            _lib.push_options()
+            e.set_python_drain(_drain_python_side)
+    return e
+
+
+def _push_config():
+    e = _EXT[0]
+    if e:
+        e.configure({"safe": 0, "async": 1, "blocking": 2}[_MODE], {"repair": 0, "raise": 1}[_OVERFLOW],
+                    _HEADROOM["instances"], _HEADROOM["chunks"], _SAFE_BYTES)
+
+
+def _drain_python_side(index):
+    """Called by the compiled binding: at its first forward on a device (this side's state -- a pinned allocation -- must
+    exist before anybody captures a HIP graph: capture forbids the allocation) and while this side has unread reports."""
+    device_state(torch.device("cuda", index)).drain(_from_ext=True)
 
 _WORDS = {}  # slot pointer -> (numpy view of its device's status block, index of the slot's first word)
 _MODE = os.environ.get("MGS_FORWARD_MODE", "safe")  # "safe" | "async" | "blocking"
@@ -54,6 +99,7 @@ def set_forward_mode(mode: str):
     if mode not in ("safe", "async", "blocking"):
         raise ValueError("forward mode is 'safe', 'async' or 'blocking'")
     old, _MODE = _MODE, mode
+    _push_config()
     return old
 
 
@@ -75,6 +121,7 @@ def set_overflow_policy(policy: str):
     if policy not in ("repair", "raise"):
         raise ValueError("overflow policy is 'repair' or 'raise'")
     old, _OVERFLOW = _OVERFLOW, policy
+    _push_config()
     return old
 
 
@@ -106,6 +153,7 @@ def set_safe_workspace(megabytes: float):
     """Largest worst-case workspace (MB) the asynchronous forward simply allocates instead of guessing from earlier calls."""
     global _SAFE_BYTES
     _SAFE_BYTES = int(float(megabytes) * (1 << 20))
+    _push_config()
 
 
 def safe_bytes() -> int:
@@ -119,17 +167,19 @@ def set_headroom(instances: float = None, chunks: float = None):
             if not v >= 1.0:
                 raise ValueError("head-room factors are >= 1")
             _HEADROOM[k] = float(v)
+    _push_config()
 
 
 class Pending:
     """One forward whose device report has not been read yet."""
-    __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "rc", "captured", "recoverable", "recovered",
-                 "backward_enqueued", "tag", "cap", "pool", "words")
+    __slots__ = ("a", "V", "slot_ptr", "key", "num_rendered", "chunks_used", "ref_rendered", "rc", "captured", "recoverable",
+                 "recovered", "backward_enqueued", "tag", "cap", "pool", "words")
 
     def __init__(self, a, V, slot_ptr, key, captured=False, recoverable=False):
         self.a, self.V, self.slot_ptr, self.key = a, V, slot_ptr, key
         self.words = _WORDS.get(slot_ptr)  # (numpy view of the status block, index of word 0) for a cheap "anything yet?"
-        self.num_rendered = self.chunks_used = -1
+        self.num_rendered = self.chunks_used = -1   # instances BINNED (what sizes a workspace), chunk records used
+        self.ref_rendered = -1                      # the reference's num_rendered (3-sigma rects), status word 2
         self.rc = _lib.MGS_PENDING
         self.captured = captured
         self.recoverable = recoverable    # a backward will follow and can re-render (manigaussian_amd._C.recover_forward)
@@ -148,31 +198,64 @@ class Pending:
         if w is not None and w[0][w[1]] == -1 and w[0][w[1] + 1] == -1:  # both words still "pending": no call into the library
             return self.rc
         L = _lib.lib()
-        nr, ch = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        nr, ch, ref = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1)
         if self.V:
-            rc = L.mgs_forward_result_views(ctypes.byref(self.a), self.V, self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch))
+            rc = L.mgs_forward_result_views(ctypes.byref(self.a), self.V, self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch),
+                                            ctypes.byref(ref))
         else:
-            rc = L.mgs_forward_result(ctypes.byref(self.a), self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch))
+            rc = L.mgs_forward_result(ctypes.byref(self.a), self.slot_ptr, ctypes.byref(nr), ctypes.byref(ch), ctypes.byref(ref))
         if nr.value >= 0:
             self.num_rendered = nr.value
         if ch.value >= 0:
             self.chunks_used = ch.value
+        if ref.value >= 0:
+            self.ref_rendered = ref.value
         if rc != _lib.MGS_PENDING:
             self.rc = rc
         return rc
 
 
+class _Marks(collections.abc.MutableMapping):
+    """The marks of one device when the compiled binding is loaded: ONE store, in the binding, shared by its hot path and by
+    this shim (a shape warmed up through either is known to both).  Values are [instances, chunk records or None] lists,
+    copies -- assign to change one."""
+
+    def __init__(self, e, index):
+        self.e, self.index = e, index
+
+    def __getitem__(self, key):
+        v = self.e.marks_get(self.index, tuple(key))
+        if v is None:
+            raise KeyError(key)
+        return v
+
+    def __setitem__(self, key, value):
+        self.e.marks_set(self.index, tuple(key), int(value[0]), None if value[1] is None else int(value[1]))
+
+    def __delitem__(self, key):
+        if not self.e.marks_del(self.index, tuple(key)):
+            raise KeyError(key)
+
+    def __iter__(self):
+        return iter(self.e.marks_keys(self.index))
+
+    def __len__(self):
+        return len(self.e.marks_keys(self.index))
+
+
 class DeviceState:
     def __init__(self, dev):
         self.dev = dev
-        self.status = torch.full((2 * NSLOTS,), -1, dtype=torch.int64).pin_memory()
+        self.status = torch.full((SLOT_WORDS * NSLOTS,), -1, dtype=torch.int64).pin_memory()
         self.base_ptr = self.status.data_ptr()
         words = self.status.numpy()
         for i in range(NSLOTS):
-            _WORDS[self.base_ptr + 16 * i] = (words, 2 * i)
+            _WORDS[self.base_ptr + SLOT_BYTES * i] = (words, SLOT_WORDS * i)
         self.reserved = set()  # slots held by captured graphs
         self.next_slot = 0
-        self.marks = {}      # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
+        # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
+        e = ext()
+        self.marks = _Marks(e, dev.index if dev.index is not None else torch.cuda.current_device()) if e else {}
         self.pending = collections.deque()
         self.captured = []   # forwards recorded into HIP graphs: their slots stay reserved, check_status() reads them
         self.deferred = collections.deque(maxlen=64)  # overflowed forwards whose backward will re-render (diagnostics)
@@ -185,7 +268,7 @@ class DeviceState:
             for _ in range(NSLOTS):
                 i = self.next_slot
                 self.next_slot = (i + 1) % NSLOTS
-                ptr = self.base_ptr + 16 * i
+                ptr = self.base_ptr + SLOT_BYTES * i
                 if not reserved or ptr not in reserved:
                     break
             else:
@@ -201,6 +284,9 @@ class DeviceState:
                 self.reserved.add(pending.slot_ptr)
             else:
                 self.pending.append(pending)
+                e = _EXT[0]
+                if e:  # the binding's hot path looks at this side's reports too while some are outstanding
+                    e.set_python_pending(len(self.pending))
 
     # ---- high-water marks ---------------------------------------------------------------------------------------
     def guess(self, key):
@@ -211,18 +297,22 @@ class DeviceState:
         return int(m[0] * _HEADROOM["instances"]) + 4096, int(m[1] * _HEADROOM["chunks"]) + 64
 
     def learn(self, key, R=None, chunks=None, pool_unknown=False):
-        m = self.marks.setdefault(key, [0, None])
+        m = list(self.marks.get(key) or (0, None))
         if R is not None and R > m[0]:
             m[0] = R
         if pool_unknown:
             m[1] = None
         elif chunks is not None and (m[1] is None or chunks > m[1]):
             m[1] = chunks
+        self.marks[key] = m
 
     # ---- reports --------------------------------------------------------------------------------------------------
-    def drain(self, wait=False):
+    def drain(self, wait=False, _from_ext=False):
         """Read every report that has arrived (wait=True: all of them, synchronising with the device once if one is still
         outstanding).  Raises if a forward overflowed its workspace or finished without reporting."""
+        e = _EXT[0]
+        if e and not _from_ext:  # reports of forwards the compiled binding enqueued on this device
+            e.check_status(self.dev.index if self.dev.index is not None else torch.cuda.current_device(), wait)
         if not self.pending:
             return
         failed = None
@@ -246,6 +336,8 @@ class DeviceState:
                     continue
                 failed = self._account(p, rc) or failed
             self.pending.extendleft(reversed(keep))  # ahead of anything appended meanwhile (nothing: we hold the lock)
+            if e:
+                e.set_python_pending(len(self.pending))
         if failed:
             raise RuntimeError(failed)
 
@@ -305,8 +397,19 @@ def check_status(device=None, wait=True):
     """Read the outstanding forward reports of `device` (default: all devices used so far), waiting for them unless
     wait=False, and raise if one of them -- or a forward replayed from a captured HIP graph -- overflowed its workspace.
     A training loop calls this wherever it synchronises anyway (logging a loss, an optimizer step)."""
+    seen = set()
     for dev, st in list(_STATES.items()):
         if device is not None and torch.device(device) != dev:
             continue
-        st.drain(wait=wait)
+        st.drain(wait=wait)  # (drains the compiled binding's reports of the device too)
         st.check_captured()
+        seen.add(dev.index)
+    e = _EXT[0]
+    if e:  # devices only the compiled binding has used
+        if device is None:
+            e.check_status(-1, wait)
+        else:
+            d = torch.device(device)
+            idx = d.index if d.index is not None else torch.cuda.current_device()
+            if idx not in seen:
+                e.check_status(idx, wait)

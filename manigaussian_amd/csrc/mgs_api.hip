@@ -47,7 +47,9 @@ static Options options_of(const MgsRasterArgs* a) {
     o.tight_bins = a->opt.tight_bins; o.fast_exp = a->opt.fast_exp; o.exact_cull = a->opt.exact_cull;
     o.bin_mode = a->opt.bin_mode ? 1 : 0; o.gm_waves = a->opt.gm_waves == 8 ? 8 : 16; o.dbg = a->opt.dbg;
     o.seg = (a->opt.seg == 512 || a->opt.seg == 1024 || a->opt.seg == 4096) ? a->opt.seg : 2048;
+    o.table_init = a->opt.table_init ? 1 : 0;
   }
+  if (a && a->debug) o.table_init = 1;  // a debugged device may hold any workgroup: no workgroup waits for another
   return o;
 }
 
@@ -163,7 +165,7 @@ void mgs_options_default(MgsOptions* o) {
   if (!o) return;
   const Options d;
   o->set = 1; o->tight_bins = d.tight_bins; o->fast_exp = d.fast_exp; o->exact_cull = d.exact_cull;
-  o->bin_mode = d.bin_mode; o->seg = d.seg; o->gm_waves = d.gm_waves; o->dbg = d.dbg;
+  o->bin_mode = d.bin_mode; o->seg = d.seg; o->gm_waves = d.gm_waves; o->dbg = d.dbg; o->table_init = d.table_init;
 }
 
 int mgs_set_option(const char* key, int value) {
@@ -251,9 +253,15 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
   p.viewmatrix = a->viewmatrix; p.projmatrix = a->projmatrix; p.campos = a->campos;
   lds = lds_tables(o, p.tiles_x * p.tiles_y);
-  if (!lds) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");  // (else: the preprocess does it)
-  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
-  im.nonce = lds ? p.nonce : 0ull;
+  // LDS tables, table_init 0: workgroup 0 of the preprocess launch zeroes the tables and the others wait for its nonce (one
+  // launch fewer; relies on workgroup 0 being dispatched first, bounded wait).  Otherwise a zero-fill launch of its own, ahead
+  // of the preprocess in stream order: nonce 0, no workgroup waits for another.
+  const bool handshake = lds && !o.table_init;
+  if (!handshake) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
+  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready;
+  p.nonce = handshake ? next_nonce() : 0ull;
+  p.wg0_delay = (o.dbg & 512) ? 100 : 0;
+  im.nonce = p.nonce;
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
     if ((reinterpret_cast<uintptr_t>(a->bwd_accum) & 15u) || (a->bwd_accum_bytes & 15u)) {
@@ -299,7 +307,8 @@ static int read_count_blocking(const GeomView& g, const ImgView& im, hipStream_t
 static inline bool status_arrived(uint64_t w, uint32_t tag) { return w != kStatusPending && (uint32_t)(w >> 48) == (tag & 0xffffu); }
 
 // Wait for word 0 = {tag, flags, R} on the pinned status block (written by the binning kernel right after the preprocess).
-static int wait_status(uint64_t* host_status, uint32_t tag, hipStream_t stream, uint32_t* R, uint32_t* fl) {
+// *R_ref: the reference's 3-sigma-rect count from word 2, which the device stores BEFORE word 0 (release order).
+static int wait_status(uint64_t* host_status, uint32_t tag, hipStream_t stream, uint32_t* R, uint32_t* fl, uint32_t* R_ref) {
   volatile uint64_t* hs = host_status;
   uint64_t st = *hs;
   for (uint64_t spins = 0; !status_arrived(st, tag); spins++) {
@@ -316,6 +325,10 @@ static int wait_status(uint64_t* host_status, uint32_t tag, hipStream_t stream, 
     st = *hs;
   }
   *R = (uint32_t)st; *fl = (uint32_t)(st >> 32) & 0xffffu;
+  uint64_t w2 = hs[2];
+  for (int spins = 0; !status_arrived(w2, tag) && spins < (1 << 20); spins++) { __builtin_ia32_pause(); w2 = hs[2]; }
+  if (!status_arrived(w2, tag)) { set_error("forward reported its instance count without the reference count"); return MGS_ERR_HIP; }
+  if (R_ref) *R_ref = (uint32_t)w2;
   return MGS_OK;
 }
 
@@ -333,7 +346,7 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
   const int F = a->include_feature ? a->F : 0;
   r.W = a->W; r.H = a->H; r.tiles_x = (a->W + TILE - 1) / TILE; r.tiles_y = (a->H + TILE - 1) / TILE;
   r.F = F; r.include_feature = F > 0;
-  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg;
+  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg & ~512;
   r.nwf = fwd_waves(F, r.tiles_x * r.tiles_y);
   r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
   r.bg = a->background;
@@ -445,15 +458,16 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   if (rc || done) {
     if (!rc && host_status) {  // P == 0: nothing will report; leave a completed status behind
       const uint64_t w = (uint64_t)(a->status_tag & 0xffffu) << 48;
-      host_status[0] = w; host_status[1] = w;
+      host_status[0] = w; host_status[1] = w; host_status[2] = w;
     }
     return rc;
   }
-  const Options o = options_of(a);
+  Options o = options_of(a);
   GeomView g; ImgView im; bool lds;
   const int F = a->include_feature ? a->F : 0;
   const BinShape bs = bin_shape(a, num_tiles(a->W, a->H), F);
   if (!a->binning || bs.cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  for (int attempt = 0;; attempt++) {
   rc = enqueue_preprocess(a, o, radii, stream, g, im, lds);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
@@ -467,41 +481,54 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
     if (rc) return rc;
     *num_rendered = (int32_t)R_ref;  // the reference's integer; the workspace has to hold the R instances actually binned
     if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
-    if (host_status) {  // (debug: both words are reported by the kernels as usual)
+    if (host_status) {  // (debug: the words are reported by the kernels as usual)
       volatile uint64_t* hs = host_status;
-      hs[0] = kStatusPending; hs[1] = kStatusPending;
+      hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
     }
     return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, 0ull, stream);
   }
-  // sync-free: everything is enqueued; the binning kernel stores {tag, flags, R} to the mapped host word as soon as the
-  // preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
+  // sync-free: everything is enqueued; the binning kernel stores {tag, reference count} and {tag, flags, R} to the mapped host
+  // words as soon as the preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
   volatile uint64_t* hs = host_status;
-  hs[0] = kStatusPending; hs[1] = kStatusPending;
+  hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
   rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, im.nonce, stream);
   if (rc) return rc;
   if (a->async_forward) { *num_rendered = -1; return MGS_OK; }  // the caller reads mgs_forward_result later
-  rc = wait_status(host_status, a->status_tag, stream, &R, &fl);
+  // Wait for the PREPROCESS only: word 0 arrives when the bin scatter starts; binning and render run on while this call
+  // returns.  The reference's integer comes through word 2 of the same block (round 4 read it back with a copy + stream
+  // synchronise, i.e. waited for the whole render).
+  uint32_t R_ref = 0;
+  rc = wait_status(host_status, a->status_tag, stream, &R, &fl, &R_ref);
   if (rc) return rc;
+  if ((fl & 2u) && attempt == 0 && !o.table_init) {
+    // A preprocess workgroup gave up waiting for the zeroed tables (workgroup 0 of the launch made no progress for about a
+    // second): nothing was binned.  Run the forward again with the tables zeroed by a launch of their own -- no workgroup
+    // waits for another on that path.  (The first run's kernels still report through the same words: drain them first.)
+    MGS_HIP(hipStreamSynchronize(stream), "stream sync before the hand-shake retry");
+    o.table_init = 1; o.dbg &= ~512;
+    continue;
+  }
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  {  // a blocking call returns the reference's integer (one more 4-byte read-back; the asynchronous path never does this)
-    uint32_t ref = 0;
-    MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
-    MGS_HIP(hipStreamSynchronize(stream), "stream sync");
-    *num_rendered = (int32_t)ref;
-  }
+  *num_rendered = (int32_t)R_ref;
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
+  }
 }
 
 static int forward_result_T(const MgsRasterArgs* a, int T, const uint64_t* host_status, int32_t* num_rendered,
-                            int32_t* chunks_used) {
+                            int32_t* chunks_used, int32_t* ref_rendered) {
   if (num_rendered) *num_rendered = -1;
   if (chunks_used) *chunks_used = -1;
+  if (ref_rendered) *ref_rendered = -1;
   if (!a || !host_status) { set_error("forward_result: NULL argument"); return MGS_ERR_INVALID_ARG; }
   const volatile uint64_t* hs = host_status;
   const uint64_t w0 = hs[0], w1 = hs[1];
   const bool a0 = status_arrived(w0, a->status_tag), a1 = status_arrived(w1, a->status_tag);
   if (a0 && num_rendered) *num_rendered = (int32_t)(uint32_t)w0;
+  if (a0 && ref_rendered) {  // (stored before word 0: arrived if word 0 has)
+    const uint64_t w2 = hs[2];
+    if (status_arrived(w2, a->status_tag)) *ref_rendered = (int32_t)(uint32_t)w2;
+  }
   if (a1 && chunks_used) *chunks_used = (int32_t)(uint32_t)w1;
   if (a0) {
     const int rc = check_prefiltered((uint32_t)(w0 >> 32) & 0xffffu);
@@ -515,9 +542,10 @@ static int forward_result_T(const MgsRasterArgs* a, int T, const uint64_t* host_
   if ((uint32_t)(w1 >> 32) & 1u) return MGS_NEED_CAPACITY;  // the chunk pool overflowed
   return MGS_OK;
 }
-int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used) {
+int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int32_t* num_rendered, int32_t* chunks_used,
+                       int32_t* ref_rendered) {
   if (!a) { set_error("forward_result: NULL argument"); return MGS_ERR_INVALID_ARG; }
-  return forward_result_T(a, num_tiles(a->W, a->H), host_status, num_rendered, chunks_used);
+  return forward_result_T(a, num_tiles(a->W, a->H), host_status, num_rendered, chunks_used, ref_rendered);
 }
 
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t R, const int32_t* radii, const float* dL_dout_color,
@@ -682,7 +710,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     MGS_HIP(launch_zero_bytes(out_color, (size_t)V * 3 * N * sizeof(float), stream), "memset out_color");
     if (F > 0) MGS_HIP(launch_zero_bytes(out_feature, (size_t)V * F * N * sizeof(float), stream), "memset out_feature");
     const uint64_t w = (uint64_t)(a->status_tag & 0xffffu) << 48;
-    host_status[0] = w; host_status[1] = w;
+    host_status[0] = w; host_status[1] = w; host_status[2] = w;
     return MGS_OK;
   }
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
@@ -721,14 +749,17 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
   const bool lds = lds_tables(o, at.T);
-  if (!lds) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
+  const bool handshake = lds && !o.table_init;  // (see enqueue_preprocess)
+  if (!handshake) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
   p.tile_hist = im.tile_hist; p.blk_base = lds ? g.blk_base : nullptr; p.ref_count = im.ref_count;
-  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready; p.nonce = next_nonce();
-  im.nonce = lds ? p.nonce : 0ull;
+  p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready;
+  p.nonce = handshake ? next_nonce() : 0ull;
+  p.wg0_delay = (o.dbg & 512) ? 100 : 0;
+  im.nonce = p.nonce;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
   volatile uint64_t* hs = host_status;
-  hs[0] = kStatusPending; hs[1] = kStatusPending;
+  hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
   const StatusSink status = {host_status, a->status_tag};
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
@@ -739,24 +770,19 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   { StageTimer t(ST_RENDER_FWD, stream);
     MGS_HIP(launch_render_fwd_dense(r, b, im, cv, out_color, out_feature, status, stream), "render forward (views)"); }
   if (a->async_forward) { *num_rendered = -1; return MGS_OK; }
-  uint32_t R = 0, fl = 0;
-  rc = wait_status(host_status, a->status_tag, stream, &R, &fl);
+  uint32_t R = 0, fl = 0, R_ref = 0;
+  rc = wait_status(host_status, a->status_tag, stream, &R, &fl, &R_ref);  // (the preprocess only: see mgs_rasterize_forward)
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  {
-    uint32_t ref = 0;
-    MGS_HIP(hipMemcpyAsync(&ref, im.ref_count, sizeof(ref), hipMemcpyDeviceToHost, stream), "reference-count read-back");
-    MGS_HIP(hipStreamSynchronize(stream), "stream sync");
-    *num_rendered = (int32_t)ref;
-  }
+  *num_rendered = (int32_t)R_ref;
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
 }
 
 int mgs_forward_result_views(const MgsRasterArgs* a, int32_t V, const uint64_t* host_status, int32_t* num_rendered,
-                             int32_t* chunks_used) {
+                             int32_t* chunks_used, int32_t* ref_rendered) {
   if (!a || V < 1) { set_error("forward_result_views: bad argument"); return MGS_ERR_INVALID_ARG; }
-  return forward_result_T(a, atlas_of(a->W, a->H, V).T, host_status, num_rendered, chunks_used);
+  return forward_result_T(a, atlas_of(a->W, a->H, V).T, host_status, num_rendered, chunks_used, ref_rendered);
 }
 
 int mgs_rasterize_backward_views(const MgsRasterArgs* a, int32_t V, const MgsView* views, int32_t R, const int32_t* radii,

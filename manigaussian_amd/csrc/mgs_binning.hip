@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
                                                                 uint32_t seg,
                                                                 uint32_t capacity, const uint32_t* __restrict__ flags,
                                                                 uint64_t* host_status, uint32_t status_tag,
+                                                                const uint32_t* __restrict__ ref_count,
                                                                 const uint2* __restrict__ rect,
                                                                 const float* __restrict__ depths,
                                                                 const uint32_t* __restrict__ tile_hist,
@@ -109,10 +110,15 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   const bool hs_failed = ready != nullptr && nonce != 0ull && ready[1] == nonce;
   const uint32_t R = hs_failed ? 0xffffffffu : flags[FLAG_NUM_RENDERED];
   if (tables && tid == 0 && ready) *ready = 0ull;  // the preprocess's hand-shake word: "not ready" for the next launch on this buffer
-  if (tables && tid == 0 && host_status)  // report {tag, flags, R} to the host (mapped pinned memory)
+  // (ready[1], the failure mark, is read by EVERY workgroup of this launch: the segment sort, next in the chain, clears it)
+  if (tables && tid == 0 && host_status) {  // report to the host (mapped pinned memory): word 2 = {tag, the reference's
+    // 3-sigma-rect instance count} first, then word 0 = {tag, flags, R} with release order -- a host that sees word 0 sees word 2
+    __hip_atomic_store(host_status + 2, ((uint64_t)(status_tag & 0xffffu) << 48) | (uint64_t)(hs_failed ? 0u : *ref_count),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) |
                        ((uint64_t)((flags[FLAG_PREFILTERED] & 0xfffdu) | (hs_failed ? 2u : 0u)) << 32) | (hs_failed ? 0u : R),
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (R > capacity) {  // the workspace cannot hold the lists (or the hand-shake failed): publish "nothing binned", the caller retries
     if (tables) {
       for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(0u, 0u);
@@ -165,6 +171,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
 // caller's retry with a larger workspace starts here again).
 __global__ void __launch_bounds__(1024) bin_tables_kernel(int T, uint32_t seg, uint32_t capacity, const uint32_t* __restrict__ flags,
                                                           uint64_t* host_status, uint32_t status_tag,
+                                                          const uint32_t* __restrict__ ref_count,
                                                           const uint32_t* __restrict__ tile_hist,
                                                           uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ seg_base, uint4* __restrict__ seg_desc) {
@@ -173,9 +180,12 @@ __global__ void __launch_bounds__(1024) bin_tables_kernel(int T, uint32_t seg, u
   __shared__ uint32_t total;
   const int tid = threadIdx.x;
   const uint32_t R = flags[FLAG_NUM_RENDERED];
-  if (tid == 0 && host_status)
+  if (tid == 0 && host_status) {  // (word 2 = the reference's count first, then word 0 with release order: see bin_scatter_kernel)
+    __hip_atomic_store(host_status + 2, ((uint64_t)(status_tag & 0xffffu) << 48) | (uint64_t)*ref_count, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(host_status, ((uint64_t)(status_tag & 0xffffu) << 48) | ((uint64_t)(flags[FLAG_PREFILTERED] & 1u) << 32) | R,
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const bool over = R > capacity;
   uint32_t key_carry = 0, seg_carry = 0;
   for (int t0 = 0; t0 < T; t0 += LDS_TILES) {
@@ -245,11 +255,15 @@ __global__ void __launch_bounds__(SEGN / 2) bin_segsort_kernel(const uint32_t* _
                                                                 const uint4* __restrict__ seg_desc,
                                                                 const uint64_t* __restrict__ keys_unsorted,
                                                                 uint64_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ point_list) {
+                                                                uint32_t* __restrict__ point_list,
+                                                                unsigned long long* hs_fail_mark) {
   __shared__ uint64_t sk[SEGN];
   const uint32_t tid = threadIdx.x;
   const int lane = (int)(tid & 63u);
   const uint4 d = seg_desc[blockIdx.x];  // surplus workgroups read an unused (in-bounds) entry
+  // ImgView::ready[1], the preprocess's "a workgroup gave up waiting" mark: every workgroup of the bin scatter has read it
+  // (kernel boundary); cleared here so that a replayed HIP graph -- same buffer, same nonce -- does not see a stale failure
+  if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;
   if (blockIdx.x >= *n_seg) return;
   const uint32_t cnt = d.y;
   const size_t base = d.x;
@@ -331,7 +345,8 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_segsort4_kernel(const uint32_t
                                                                   const uint4* __restrict__ seg_desc,
                                                                   const uint64_t* __restrict__ keys_unsorted,
                                                                   uint64_t* __restrict__ keys,
-                                                                  uint32_t* __restrict__ point_list) {
+                                                                  uint32_t* __restrict__ point_list,
+                                                                  unsigned long long* hs_fail_mark) {
   static_assert(KPT == 2 || KPT == 4, "two or four keys per lane");
   constexpr uint32_t NT = SEGN / KPT;
   constexpr uint32_t LDS_MIN = 64u * KPT;  // smallest compare-exchange distance that crosses waves
@@ -340,6 +355,7 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_segsort4_kernel(const uint32_t
   const int lane = (int)(tid & 63u);
   const uint4 d = seg_desc[blockIdx.x];  // surplus workgroups read an unused (in-bounds) entry
   const uint32_t nseg = *n_seg;
+  if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;  // (see bin_segsort_kernel)
   if (blockIdx.x >= nseg) return;
   const uint32_t cnt = d.y;
   const size_t base = d.x;
@@ -537,10 +553,10 @@ static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im,
   if (which == 1) {
     if constexpr (KPT == 4)
       hipLaunchKernelGGL((bin_segsort4_kernel<SEGN, 4>), dim3(n_segments), dim3(SEGN / 4), 0, s, im.seg_base + T, b.seg_desc,
-                         b.keys_unsorted, b.keys, b.point_list);
+                         b.keys_unsorted, b.keys, b.point_list, im.ready ? im.ready + 1 : nullptr);
     else
       hipLaunchKernelGGL(bin_segsort_kernel<SEGN>, dim3(n_segments), dim3(SEGN / 2), 0, s, im.seg_base + T, b.seg_desc,
-                         b.keys_unsorted, b.keys, b.point_list);
+                         b.keys_unsorted, b.keys, b.point_list, im.ready ? im.ready + 1 : nullptr);
   } else
     hipLaunchKernelGGL((bin_merge_emit_kernel<SEGN, KPT>), dim3((n_segments + 63) / 64 * 64), dim3(SEGN / KPT), 0, s, im.seg_base + T,  // (XCD map)
                        b.seg_desc, b.keys, b.point_list);
@@ -554,7 +570,7 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, con
   const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
   if (which == 0 && !lds_tables) {
     hipLaunchKernelGGL(bin_tables_kernel, dim3(1), dim3(1024), 0, s, T, (uint32_t)seg, (uint32_t)capacity, im.flags, status.host,
-                       status.tag, im.tile_hist, im.cursor, im.ranges, im.seg_base, b.seg_desc);
+                       status.tag, im.ref_count, im.tile_hist, im.cursor, im.ranges, im.seg_base, b.seg_desc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = V * Pg;
@@ -565,7 +581,7 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, con
   if (which == 0) {
     // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
-                       tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, g.rect, g.depths,
+                       tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, im.ref_count, g.rect, g.depths,
                        im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready, im.nonce);
     return hipGetLastError();
   }

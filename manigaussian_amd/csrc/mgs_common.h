@@ -201,6 +201,7 @@ struct Options {
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
   int gm_waves = 16;       // waves per workgroup of the render backward (8 or 16)
   int dbg = 0;             // see RenderArgs::dbg
+  int table_init = 0;      // 0: the preprocess launch zeroes its tables itself (workgroup 0 + hand-shake); 1: a zero-fill launch first
 };
 // process-wide DIAGNOSTIC state only (never results or layouts): stage timers
 int profile_level();
@@ -229,7 +230,8 @@ struct FwdPreArgs {
   uint32_t* tables;     // LDS tables: the flags | tile_hist | seg_base block, zeroed by workgroup 0 of this launch
   uint32_t tables_words;
   unsigned long long* ready;  // ImgView::ready
-  unsigned long long nonce;   // this launch's (non-zero) nonce
+  unsigned long long nonce;   // this launch's (non-zero) nonce; 0: the tables were zeroed by an earlier launch, no hand-shake
+  int wg0_delay;              // test hook (MgsOptions.dbg & 512): workgroup 0 sleeps this many x ~3 us before it zeroes the tables
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int prefiltered, tight_bins;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;

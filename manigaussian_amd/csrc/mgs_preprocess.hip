@@ -205,8 +205,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   // on the tables, at the very end of the kernel -- ten microseconds later.  (Workgroups are dispatched in index order, so
   // workgroup 0 runs before anyone can wait for it.)  This replaces a zero-fill launch per forward; the bin scatter kernel
   // resets the word, so a replayed HIP graph -- same nonce, same buffer -- starts from "not ready" again.
+  // a.nonce == 0 (MgsOptions.table_init = 1): an EARLIER LAUNCH of the stream zeroed the tables; workgroup 0 has nothing to do
+  // and nobody waits for anybody -- correct by construction, one launch more per forward.
   if constexpr (HIST) {
     if (blockIdx.x == 0) {
+      if (a.nonce == 0ull) return;
+      for (int i = 0; i < a.wg0_delay; i++) __builtin_amdgcn_s_sleep(127);  // (test hook: the workers must wait this out)
       for (uint32_t i = threadIdx.x; i < a.tables_words; i += blockDim.x) a.tables[i] = 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
@@ -255,7 +259,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   // thread 0 looks at the hand-shake word NOW (no wait: the value is examined at the end of the kernel, microseconds later,
   // when workgroup 0's store has long arrived -- a second look is only needed if this one came too early)
   unsigned long long seen = 0ull;
-  if (HIST && threadIdx.x == 0) seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (HIST && threadIdx.x == 0 && a.nonce != 0ull) seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (gi < a.Pg) {
   const float* __restrict__ vm = batch ? a.cam[v].viewmatrix : a.viewmatrix;
   const float* __restrict__ pm = batch ? a.cam[v].projmatrix : a.projmatrix;
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
       //  the tables and leaves the launch's nonce in ready[1]; the bin scatter kernel, next in the chain, then publishes
       //  "nothing binned" and reports the failure through the status word, so that the host raises MGS_ERR_HIP for THIS
       //  call instead of losing the HIP context to a trap)
-      for (uint32_t polls = 0; seen != a.nonce; polls++) {
+      for (uint32_t polls = 0; a.nonce != 0ull && seen != a.nonce; polls++) {
         if (polls == (1u << 23)) {
           s_fail = 1u;
           __hip_atomic_store(a.ready + 1, a.nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

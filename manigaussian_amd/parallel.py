@@ -16,6 +16,25 @@ import torch
 import torch.distributed as dist
 
 
+# Dry run of the collectives (bench.py --dry-collectives, tests/test_parallel.py): with a process group of ONE rank every
+# collective below is the identity and is skipped -- unless this flag is set, in which case the exact call sequence of the N > 1
+# path (sub-group creation, padded all-gather / reduce-scatter of device tensors, the flat-bucket all-reduce) is issued to the
+# backend anyway.  On a single MI355X that runs the RCCL branches on hardware; it measures the calls' cost, not transport.
+_DRY = [False]
+
+
+def set_dry_collectives(on: bool) -> bool:
+    old, _DRY[0] = _DRY[0], bool(on)
+    return old
+
+
+def collectives_active(group=None) -> bool:
+    """Is there somebody to talk to (a process group of more than one rank -- or a dry run)?"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return _DRY[0] or dist.get_world_size(group) > 1
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Round-robin: rank g takes items {i : i mod world == g}."""
     return list(range(rank, n_items, world))
@@ -43,7 +62,7 @@ class GradBucket:
             self.params[n].grad = self.views[n]
 
     def all_reduce(self, group=None, async_op: bool = False):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if collectives_active(group):
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
@@ -87,7 +106,7 @@ def flat_alias(grads: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
 def all_reduce_grads(grads: Sequence[torch.Tensor], group=None, async_op: bool = False):
     """ONE sum all-reduce over the gradients of a step.  In place on the shared allocation when the gradients
     alias one buffer (no staging copy); otherwise through a flat staging bucket that is scattered back."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_active(group):
         return None
     flat = flat_alias(grads)
     if flat is not None:
@@ -118,7 +137,7 @@ def sparse_all_reduce_grads(grads: Sequence[torch.Tensor], visible: torch.Tensor
     per-Gaussian gradients; not weight decay, not anything that flowed through an MLP (check_rows=True verifies it, at the
     price of a pass over the gradients and a host read).  Returns K = |union of the visible sets| (the local visible count
     without a process group: the union over one rank)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_active(group):
         return int(visible.sum().item())
     gs = [g for g in grads if g is not None and g.numel() > 0]
     P = int(visible.numel())
@@ -222,7 +241,7 @@ class _GatherRows(torch.autograd.Function):
 
 def gather_rows(local: torch.Tensor, n_points: int, group=None) -> torch.Tensor:
     """Differentiable all-gather of per-point rows (see _GatherRows); the identity without a process group of > 1 ranks."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_active(group):
         return local
     return _GatherRows.apply(local, n_points, group)
 
@@ -243,7 +262,7 @@ def sharded_deformation(field, point_latent, z_feature, xyz, sh, rot, scale, opa
     assemble = assemble or deform.assemble_deform_input
     apply = apply or deform.deform_apply
     P = xyz.shape[0]
-    sharded = group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    sharded = group is not None and collectives_active(group)
     lo, hi, _ = point_shard(P, dist.get_rank(group), dist.get_world_size(group)) if sharded else (0, P, P)
 
     def rows(t, local_ok=False):
@@ -298,6 +317,10 @@ class DynamicPlan:
             raise ValueError(f"{n_views} views do not divide over the {self.group_size} ranks that share a timestep")
         self.views = list(range(self.group_rank, n_views, self.group_size))
         self.group = None
+        if _DRY[0] and self.group_size == 1 and dist.is_available() and dist.is_initialized():
+            # dry run: a sub-group of this one rank stands in for "the ranks that share my timestep" (new_group, the padded
+            # all-gather / reduce-scatter and their autograd glue all execute; the plan's shares stay those of one rank)
+            self.group = dist.new_group([rank])
         if self.group_size > 1:
             if self.group_size == world:
                 self.group = dist.group.WORLD
@@ -315,7 +338,7 @@ class DynamicPlan:
 
     def describe(self, n_points: int) -> dict:
         lo, hi = self.point_rows(n_points)
-        sharded = self.group_size > 1
+        sharded = self.group_size > 1 or self.group is not None  # (a dry run's one-rank sub-group issues them too)
         return {"timesteps_on_this_rank": len(self.timesteps), "views_per_timestep_on_this_rank": len(self.views),
                 "ranks_sharing_a_timestep": self.group_size, "mlp_points_per_rank": hi - lo,
                 "all_gather_bytes_per_timestep": 28 * n_points if sharded else 0,

@@ -107,6 +107,21 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, language_feature_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
+    # The compiled binding first (csrc/mgs_torch.cpp: the reference's own binding is compiled too,
+    # RAST/rasterize_points.cu:35-225): marshalling, allocation and the autograd node in C++ over the same C ABI.  It returns
+    # None for calls it does not handle (debug / prefiltered, HIP-graph capture, padded feature widths, non-contiguous or
+    # non-fp32 inputs, the first calls of a shape in "async" mode, "blocking" mode): the ctypes shim below does those.
+    ext = _C.compiled()
+    if ext is not None:
+        s = raster_settings
+        try:
+            out = ext.rasterize(means3D, means2D, sh, colors_precomp, language_feature_precomp, opacities, scales, rotations,
+                                cov3Ds_precomp, s.bg, s.viewmatrix, s.projmatrix, s.campos, s.image_height, s.image_width,
+                                s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.prefiltered, s.debug, s.include_feature)
+        except TypeError:  # an argument the binding's signature does not convert (None for a tensor, ...): the shim's rules apply
+            out = None
+        if out is not None:
+            return out
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, language_feature_precomp, opacities,
                                      scales, rotations, cov3Ds_precomp, raster_settings)
 

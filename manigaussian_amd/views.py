@@ -123,8 +123,8 @@ class _RasterizeViews(torch.autograd.Function):
                     a.bwd_accum, a.bwd_accum_bytes = grad_buffer.data_ptr(), accum_bytes
                 rc, R = _C._launch_forward(L, a, (views, V), radii, out_color, out_feat if inc else None, slot_ptr,
                                            _C._stream(dev))
-                if rc == _lib.MGS_NEED_CAPACITY:  # (blocking path) the guess was too small: run the batch again with room for R
-                    st.learn(key, R)
+                if rc == _lib.MGS_NEED_CAPACITY:  # (waiting path) the guess was too small: run the batch again with room for R
+                    st.learn(key, _C._binned_now(slot_ptr))  # (R is the reference's count; the marks hold binned counts)
                     cap, pool = R + R // 4 + 4096, 0
                     continue
                 _lib.check(rc, "rasterize views")

@@ -22,7 +22,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # stock build (3 feature channels, config.h:16) and the same sources rebuilt at 32 channels (oracle/Makefile)
-LIB_PATHS = {3: os.path.join(_HERE, "_ref", "libmgs_ref.so"), 32: os.path.join(_HERE, "_ref", "libmgs_ref_f32.so")}
+LIB_PATHS = {3: os.path.join(_HERE, "_ref", "libmgs_ref.so"), 32: os.path.join(_HERE, "_ref", "libmgs_ref_f32.so"),
+             8: os.path.join(_HERE, "_ref", "libmgs_ref_f8.so")}
 LIB_PATH = LIB_PATHS[3]
 _libs = {}
 c_fp = ctypes.POINTER(ctypes.c_float)

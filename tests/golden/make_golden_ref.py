@@ -6,8 +6,12 @@ rasterizer_impl.cu compiled unmodified for gfx950.  It needs a GPU, so it runs o
 
   gpurun -- 'python tests/golden/make_golden_ref.py gpurun_out/golden_ref'      # then copy into tests/golden/ref/
 
-Every case has F = 3 feature channels, the reference build's fixed width (RAST/cuda_rasterizer/config.h:16).  Inputs
-are regenerated from `case` by tests/util.scene_case, and stored as well so a drift of the generator is caught.
+The stock reference build has F = 3 feature channels (RAST/cuda_rasterizer/config.h:15-16); the F = 32 and F = 8 cases come
+from the same three sources rebuilt at that width (oracle/Makefile, REF_WIDTH: config.h's macros given on the command line) --
+BASELINE configs[2]'s width pinned by COMMITTED vectors, not only by the live test that needs the prebuilt library.  The
+scale_modifier cases exercise computeCov3D's `mod` (forward.cu:122-126) and the cov3D backward, whose dL_dscale deliberately
+omits it (backward.cu:295,325-327).  Inputs are regenerated from `case` by tests/util.scene_case, and stored as well so a
+drift of the generator is caught.  `ONLY=name1,name2` regenerates a subset.
 """
 import os
 import sys
@@ -29,6 +33,13 @@ CASES = {
     "ref_sh2_f3_ragged_100x52": dict(P=1500, F=3, M=9, sh_degree=2, W=100, H=52, neg=True, bg=(1.0, 1.0, 1.0), seed=3,
                                      cam_index=2),
     "ref_sh_f3_128x128_p4000": dict(P=4000, F=3, W=128, H=128, neg=True, bg=(0.1, 0.2, 0.3), seed=7, cam_index=0),
+    # round 5: other feature widths (the reference rebuilt), scale_modifier != 1
+    "ref_sh_f32_negfocal_64x64": dict(P=900, F=32, W=64, H=64, neg=True, bg=(0.1, 0.2, 0.3), seed=21),
+    "ref_sh2_f32_ragged_80x48": dict(P=1200, F=32, M=9, sh_degree=2, W=80, H=48, neg=False, bg=(0.0, 0.0, 0.0), seed=22,
+                                     cam_index=2),
+    "ref_sh_f8_48x48": dict(P=500, F=8, W=48, H=48, neg=True, bg=(0.2, 0.0, 0.1), seed=23, cam_index=0),
+    "ref_scalemod0p5_f3_64x64": dict(P=800, F=3, W=64, H=64, neg=True, bg=(0.1, 0.2, 0.3), seed=24, scale_modifier=0.5),
+    "ref_scalemod2_f32_64x64": dict(P=700, F=32, W=64, H=64, neg=True, bg=(0.0, 0.0, 0.0), seed=25, scale_modifier=2.0),
 }
 
 
@@ -38,7 +49,10 @@ run_reference = util.run_reference
 def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "ref")
     os.makedirs(out_dir, exist_ok=True)
+    only = [n for n in os.environ.get("ONLY", "").split(",") if n]
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         sc, cam, kw, dC, dF = util.scene_case(**c)
         color, feat, radii, grads, R = run_reference(sc, kw, dC, dF)
         # atomics make the reference's gradients run-to-run non-deterministic at the ulp level: record the spread

@@ -1,0 +1,247 @@
+"""The compiled autograd binding (manigaussian_amd/csrc/mgs_torch.cpp -> _mgs_torch.so): what the reference's own binding is
+(RAST/rasterize_points.cu:35-225, compiled, torch types in, rasterizer out), over this repository's C ABI.  CPU: it loads, it
+shares the workspace marks with the ctypes shim, it declines what it does not handle.  GPU: it is the path an unmodified
+caller takes, its results are those of the ctypes shim (same kernels: images bit for bit, gradients to float-atomic order),
+its waiting / retry / overflow protocol, autograd corner cases."""
+import gc
+import os
+import warnings
+
+import pytest
+import torch
+
+import manigaussian_amd as mg
+from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _C, _lib, _state
+from manigaussian_amd import synthetic as syn
+
+import util
+
+
+def _ext():
+    e = _C.compiled()
+    assert e is not None, "manigaussian_amd/_mgs_torch.so is not built (make -C manigaussian_amd/csrc ext)"
+    return e
+
+
+def test_compiled_binding_loads_declines_cpu_calls_and_shares_the_marks():
+    e = _ext()
+    assert e.ABI_VERSION == _lib.ABI_VERSION and e.build_id() == _lib.build_id()
+    t = torch.zeros(4, 3)
+    before = e.counters()["declined"]
+    assert e.rasterize(t, t, t, t, t, t, t, t, t, t, t, t, t, 8, 8, 1.0, 1.0, 1.0, 1, False, False, True) is None
+    assert e.counters()["declined"] == before + 1
+    m = _state._Marks(e, 7)  # (device index 7: nothing else uses it)
+    key, vkey = (1000, 64, 64, 3, 1), ("views", 4, 1000, 64, 64, 3, 1)
+    assert key not in m and m.get(key) is None
+    m[key] = [10000, None]
+    m[vkey] = [5, 6]
+    assert m[key] == [10000, None] and m[vkey] == [5, 6] and set(m) == {key, vkey} and len(m) == 2
+    st = _state.DeviceState.__new__(_state.DeviceState)
+    st.marks = m
+    assert st.guess(key) is None             # chunk pool unknown: no guess
+    st.learn(key, R=8000, chunks=400)        # marks only grow
+    assert m[key] == [10000, 400] and st.guess(key) == (int(10000 * 1.5) + 4096, int(400 * 2.0) + 64)
+    del m[key], m[vkey]
+    assert len(m) == 0
+
+
+def _step(d, rast, dC, dF, between=None, retain=False):
+    leaves = {k: v.detach().requires_grad_(True) for k, v in d.items()}
+    m2 = torch.zeros_like(leaves["means3D"]).requires_grad_(True)
+    c, f, r = rast(leaves["means3D"], m2, leaves["opacities"], shs=leaves["shs"],
+                   language_feature_precomp=leaves["language_feature"], scales=leaves["scales"], rotations=leaves["rotations"])
+    if between is not None:
+        between()
+    inputs = list(leaves.values()) + [m2]
+    grads = torch.autograd.grad([c, f], inputs, [dC, dF], retain_graph=retain)
+    return c, f, r, grads, (leaves, m2, inputs)
+
+
+def _setup(P, F, W=128):
+    dev = torch.device("cuda:0")
+    sc, cam, kw, dC, dF = util.scene_case(P=P, F=F, W=W, H=W)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, bg=(0.1, 0.2, 0.3),
+                                                                                        device=dev)))
+    return dev, d, rast, dC.to(dev), dF.to(dev)
+
+
+def _same(a, b):
+    (c0, f0, r0, g0), (c1, f1, r1, g1) = a[:4], b[:4]
+    assert torch.equal(c1, c0) and torch.equal(f1, f0) and torch.equal(r1, r0)
+    for x, y in zip(g1, g0):
+        assert x.shape == y.shape
+        assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item() + 1e-12  # float atomics: order differs run to run
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,budget_mb", [("safe", None), ("safe", 0), ("async", 0)],
+                         ids=["safe-cannot-overflow", "safe-waits-for-the-preprocess", "async-marks"])
+def test_compiled_path_is_what_runs_and_equals_the_ctypes_shim(mode, budget_mb):
+    e = _ext()
+    dev, d, rast, dC, dF = _setup(20000, 32)
+    old_mode, old_budget = mg.set_forward_mode(mode), _state.safe_bytes()
+    if budget_mb is not None:
+        mg.set_safe_workspace(budget_mb)
+    try:
+        with _C.use_compiled(False):
+            for _ in range(3):
+                ref = _step(d, rast, dC, dF)
+                mg.check_status(dev)
+        e.counters(True)
+        for _ in range(3):
+            got = _step(d, rast, dC, dF)
+            mg.check_status(dev)
+        n = e.counters()
+        assert n["forwards"] == 3 and n["backwards"] == 3 and n["declined"] == 0, n
+        assert n["waited"] == (3 if (mode == "safe" and budget_mb == 0) else 0), n
+        assert got[0].grad_fn.name() == "MgsRasterizeBackward" and got[2].grad_fn is None
+        _same(ref, got)
+    finally:
+        mg.set_forward_mode(old_mode)
+        _state._SAFE_BYTES = old_budget
+        _state._push_config()
+
+
+@pytest.mark.gpu
+def test_compiled_wait_path_retries_when_the_scene_outgrew_its_marks_and_never_returns_incomplete_images():
+    e = _ext()
+    dev, d, rast, dC, dF = _setup(15000, 3)
+    old_mode, old_budget = mg.set_forward_mode("safe"), _state.safe_bytes()
+    mg.set_safe_workspace(0)
+    try:
+        with _C.use_compiled(False), util_forward_mode("blocking"):
+            ref = _step(d, rast, dC, dF)
+        st = _state.device_state(dev)
+        key = (15000, 128, 128, 3, 1)
+        mg.check_status(dev)
+        good = st.marks[key][0]
+        st.marks[key] = [16, None]   # far too small: the preprocess's report says so, the call bins + renders again
+        e.counters(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            got = _step(d, rast, dC, dF)
+            mg.check_status(dev)
+        n = e.counters()
+        assert n["forwards"] == 1 and n["waited"] == 1 and n["retried"] == 1, n
+        _same(ref, got)
+        assert st.marks[key][0] >= good  # learnt again: the BINNED count
+        got2 = _step(d, rast, dC, dF)
+        mg.check_status(dev)
+        assert e.counters()["retried"] == 1
+        _same(ref, got2)
+    finally:
+        mg.set_forward_mode(old_mode)
+        _state._SAFE_BYTES = old_budget
+        _state._push_config()
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def util_forward_mode(mode):
+    old = mg.set_forward_mode(mode)
+    try:
+        yield
+    finally:
+        mg.set_forward_mode(old)
+
+
+@pytest.mark.gpu
+def test_compiled_autograd_corner_cases():
+    """retain_graph (a second backward allocates and fills its accumulators), no_grad, a saved input modified in place,
+    an unused output, and no leak: the node holds its images weakly."""
+    e = _ext()
+    dev, d, rast, dC, dF = _setup(6000, 32)
+    with _C.use_compiled(False):
+        ref = _step(d, rast, dC, dF)
+    e.counters(True)
+    c, f, r, g1, (leaves, m2, inputs) = _step(d, rast, dC, dF, retain=True)
+    g2 = torch.autograd.grad([c, f], inputs, [dC, dF])
+    _same(ref, (c, f, r, g1))
+    _same(ref, (c, f, r, g2))
+    with pytest.raises(RuntimeError, match="second time"):
+        torch.autograd.grad([c, f], inputs, [dC, dF])
+    # only the colour image is differentiated: the feature cotangent is absent
+    c, f, r, _, (leaves, m2, inputs) = _step(d, rast, dC, dF, retain=True)
+    gc_only = torch.autograd.grad([c], inputs, [dC], allow_unused=True)
+    with _C.use_compiled(False):
+        c_, f_, r_, _, (lv_, m2_, in_) = _step(d, rast, dC, dF, retain=True)
+        gc_ref = torch.autograd.grad([c_], in_, [dC], allow_unused=True)
+    for x, y in zip(gc_only, gc_ref):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item() + 1e-12
+    with torch.no_grad():
+        c, f, r = rast(d["means3D"], torch.zeros_like(d["means3D"]), d["opacities"], shs=d["shs"],
+                       language_feature_precomp=d["language_feature"], scales=d["scales"], rotations=d["rotations"])
+    assert c.grad_fn is None and not c.requires_grad and torch.equal(c, ref[0])
+    # a saved input modified in place between forward and backward: autograd's own error
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in d.items()}
+    sc_ = leaves["scales"] * 1.0  # (non-leaf, so that an in-place op is legal)
+    c, f, r = rast(leaves["means3D"], torch.zeros_like(leaves["means3D"]), leaves["opacities"], shs=leaves["shs"],
+                   language_feature_precomp=leaves["language_feature"], scales=sc_, rotations=leaves["rotations"])
+    assert c.grad_fn.name() == "MgsRasterizeBackward"
+    sc_.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        (c.sum() + f.sum()).backward()
+    del c, f, r
+    mg.check_status(dev)
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated(dev)
+    for _ in range(40):
+        _step(d, rast, dC, dF)
+    mg.check_status(dev)
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(dev) - base < (8 << 20), "a forward's workspaces are not being released"
+
+
+@pytest.mark.gpu
+def test_num_rendered_is_the_reference_integer_on_every_path():
+    """blocking entry points returned the reference's 3-sigma-rect count, asynchronous handles the binned count.
+    The device now reports both (status words 0 and 2): int(handle) is the reference's integer on every path, binned() the
+    other one."""
+    dev, d, rast, dC, dF = _setup(20000, 32)
+    e_ = torch.Tensor([])
+    s = rast.raster_settings
+    R_block = _C.rasterize_gaussians(s.bg, d["means3D"], e_, d["language_feature"], d["opacities"], d["scales"], d["rotations"],
+                                     1.0, e_, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, 128, 128, d["shs"], 1,
+                                     s.campos, False, False, True)[0]
+    old = mg.set_forward_mode("async")
+    try:
+        with _C.use_compiled(False):
+            for _ in range(3):
+                c, f, r, g, _ = _step(d, rast, dC, dF, retain=True)
+                mg.check_status(dev)
+            h = c.grad_fn.num_rendered
+            assert h.pending is not None and int(h) == R_block and 0 < h.binned() <= R_block
+    finally:
+        mg.set_forward_mode(old)
+
+
+@pytest.mark.gpu
+def test_tile_tables_zeroed_by_a_launch_of_their_own_and_a_delayed_table_workgroup():
+    """VERDICT r4 item 8.  table_init = 1: a zero-fill launch ahead of the preprocess, no workgroup waits for another (what
+    debug = 1 selects by itself).  dbg = 512: workgroup 0 of the default preprocess sleeps ~0.3 ms before it zeroes the tables --
+    every working workgroup has long finished its Gaussians and waits; bins, images and gradients must be the default's, bit
+    for bit (images) -- and no MGS_ERR_HIP."""
+    dev, d, rast, dC, dF = _setup(30000, 32)
+    ref = _step(d, rast, dC, dF)
+    mg.check_status(dev)
+    for key, val in (("table_init", 1), ("dbg", 512)):
+        old = _lib.get_option(key)
+        _lib.set_option(key, val)
+        try:
+            for compiled in (True, False):
+                with _C.use_compiled(compiled):
+                    got = _step(d, rast, dC, dF)
+                    mg.check_status(dev)
+                    _same(ref, got)
+            with _C.use_compiled(False), util_forward_mode("blocking"):
+                got = _step(d, rast, dC, dF)
+                _same(ref, got)
+        finally:
+            _lib.set_option(key, old)

@@ -338,3 +338,35 @@ def test_bench_two_ranks_over_rccl():
     r, j = _bench(["--gpus", "2", "--steps", "50", "--warmup", "10", "--no-cpu-baseline"])
     assert r.returncode == 0 and j is not None, (r.stdout[-2000:], r.stderr[-3000:])
     assert j["n_gpus"] == 2 and j["distributed"]["backend"] == "nccl" and sorted(j["distributed"]["device_ids"]) == [0, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg", ["c3", "c4"])
+def test_rccl_call_sequence_runs_on_one_device(cfg):
+    """the RCCL branches of the N > 1 path (parallel.py: the in-place flat-bucket all-reduce with two
+    alternating buffers, DynamicPlan's dist.new_group, all_gather_into_tensor / reduce_scatter_tensor of DEVICE tensors and
+    their autograd glue) had only ever run over gloo through host staging.  `bench.py --dry-collectives` creates an RCCL
+    process group of ONE rank and issues the exact call sequence to the device; not skipped on a one-GPU box.  What this
+    proves: the calls are well-formed for RCCL on this stack (dtypes, contiguity, sizes, stream semantics, sub-groups); what
+    it cannot: transport over xGMI."""
+    args = ["--dry-collectives", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-reference-kernels"]
+    if cfg == "c3":
+        args += ["--P", "20000", "--mode", "graph"]  # all modes: graph replay with alternating buckets, eager, ...
+    else:
+        args += ["--config", "c4", "--P", "6000", "--mode", "eager-st", "--only-mode"]
+        os.environ["MGS_NO_GEMM_TUNING"] = "1"
+    try:
+        r, j = _bench(args, timeout=800)
+    finally:
+        os.environ.pop("MGS_NO_GEMM_TUNING", None)
+    assert r.returncode == 0 and j is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    d = j["distributed"]
+    assert d["dry_collectives"] is True and d["backend"] == "nccl" and d["world_size_seen"] == 1 and j["n_gpus"] == 1
+    assert d["allreduce_exposed_ms_per_step"] is not None and d["allreduce_bytes_per_step"] > 0
+    if cfg == "c3":
+        assert d["allreduce_bytes_per_step"] == 20000 * (3 + 1 + 12 + 3 + 4 + 32) * 4
+        assert not j.get("mode_errors"), j.get("mode_errors")
+    else:
+        part = j["config"]["partition"]
+        assert part["all_gather_bytes_per_timestep"] == 28 * 6000 and part["reduce_scatter_bytes_per_timestep"] == 28 * 6000

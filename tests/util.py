@@ -8,7 +8,7 @@ from manigaussian_amd import synthetic as syn
 
 
 def scene_case(P, F=3, M=4, W=128, H=128, neg=True, colors_precomp=False, bg=(0.1, 0.2, 0.3), sh_degree=1,
-               include_feature=True, seed=0, cam_index=1, unnormalized_rot=False, cov3d=False):
+               include_feature=True, seed=0, cam_index=1, unnormalized_rot=False, cov3d=False, scale_modifier=1.0):
     sc = syn.make_scene(P, F=F if include_feature else 0, M=M, seed=seed, colors_precomp=colors_precomp,
                         unnormalized_rot=unnormalized_rot)
     if cov3d:  # precomputed covariance instead of scale/rotation
@@ -24,7 +24,8 @@ def scene_case(P, F=3, M=4, W=128, H=128, neg=True, colors_precomp=False, bg=(0.
                                            Sg[:, 2, 2]], 1).contiguous()
     cam = syn.circle_cameras(4, W, H, negative_focal=neg)[cam_index]
     kw = syn.camera_settings_kwargs(cam, sh_degree, include_feature, bg=bg)
-    dC, dF = syn.make_cotangents(W, H, F if include_feature else 0)
+    kw["scale_modifier"] = float(scale_modifier)  # enters computeCov3D (forward.cu:122-126) and the cov3D backward, whose
+    dC, dF = syn.make_cotangents(W, H, F if include_feature else 0)  # dL_dscale omits it (backward.cu:295,325-327)
     return sc, cam, kw, dC, dF
 
 
@@ -61,10 +62,11 @@ def run_reference(sc, kw, dC, dF):
         cov3D_precomp=sc.get("cov3D_precomp"))
 
 
-def run_hip(sc, cam, dC, dF, sh_degree, include_feature, bg, device="cuda:0", debug=False):
+def run_hip(sc, cam, dC, dF, sh_degree, include_feature, bg, device="cuda:0", debug=False, scale_modifier=1.0):
     from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device(device)
     kw = syn.camera_settings_kwargs(cam, sh_degree, include_feature, bg=bg, device=dev, debug=debug)
+    kw["scale_modifier"] = float(scale_modifier)
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     P = sc["means3D"].shape[0]
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
