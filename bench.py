@@ -889,12 +889,19 @@ def main():
         print(json.dumps(out))
         if violations:
             print("bench.py: roofline fraction above 1: " + "; ".join(violations), file=sys.stderr)
-    if world > 1:
-        dist.barrier()
+    rc = 3 if (args.strict_roofline and rank == 0 and violations) else 0
     if coll_on:
-        dist.destroy_process_group()
-    if args.strict_roofline and rank == 0 and violations:
-        raise SystemExit(3)
+        # Every rank has finished (rank 0 has printed).  The process then leaves WITHOUT tearing the process group down:
+        # destroy_process_group() / interpreter exit with HIP graphs alive that captured RCCL kernels was seen to abort
+        # intermittently in ProcessGroupNCCL's background threads (round 5, one-rank dry run inside the GPU suite) -- after
+        # the result line, but a non-zero exit code is a failed run to a driver.  The OS reclaims everything.
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

@@ -52,7 +52,8 @@ for W in golden quick tests host bench configs stats pmc trace extra; do
     timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.log 2>&1; echo "bench (driver form) rc=$?"
     tail -1 $OUT/bench_driver_form.log > $OUT/bench_driver_form.json; line < $OUT/bench_driver_form.json ;;
   configs)
-    for c in ${CONFIGS:-"--config c2" "--config c5shape" "--config ref16k" "--views 4" "--views 8" "--config c4 --steps 30 --warmup 10" "--config c5 --steps 20 --warmup 8"}; do
+    IFS=';' read -ra CFGS <<< "${CONFIGS:---config c2;--config c5shape;--config ref16k;--views 4;--views 8;--config c4 --steps 30 --warmup 10;--config c5 --steps 20 --warmup 8}"
+    for c in "${CFGS[@]}"; do
       n=$(echo $c | tr -d ' -' ); n=${n#config}
       case "$c" in *"config c4"*|*"config c5 "*) cpu="" ;; *) cpu="--no-cpu-baseline" ;; esac
       timeout 1200 python bench.py $c $cpu --strict-roofline > $OUT/bench_$n.log 2>&1; echo "bench $c rc=$?"
