@@ -12,10 +12,16 @@ F=32, one look-at view per GPU per step, production negative-focal cameras, inpu
 + one backward of the rasterizer through the public GaussianRasterizer autograd API (+ one all-reduce of the per-Gaussian
 parameter gradients when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
 
-Modes (all three are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default graph):
+Modes (all are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default eager-safe):
+  eager-safe  THE DEFAULT since round 5: K plain Python steps through the public autograd API under the PACKAGE DEFAULTS --
+            forward mode "safe" (this shape waits for the preprocess's report; nothing speculative), torch's default autograd
+            threading, the compiled binding (csrc/mgs_torch.cpp): what an unmodified caller of the drop-in gets, no opt-in of
+            any kind.  Since the binding cut the host cost of a step to ~80 us the eager step is GPU-bound at every BASELINE
+            shape and a few us FASTER than a replayed graph (rounds 1-4 made `graph` the headline because the ctypes shim's
+            113-145 us of Python per step made eager host-bound).
   graph     the step captured once with torch.cuda.graph through the PUBLIC autograd API and replayed (possible because
-            nothing in the library synchronises).  The default: it needs no process-wide torch switch and is what a
-            training loop that cares about a 0.17 ms step would do; one replay costs ~7 us more than the kernels.
+            nothing in the library synchronises; needs --forward-mode async, the opt-in); one replay costs ~5 us more than
+            the kernels.
   eager-st  the Python step called K times with torch.autograd.set_multithreading_enabled(False): the backward is
             enqueued by the calling thread, the host runs ahead and the step is GPU-bound: ms_per_step == the sum of the
             kernel durations of rocprofv3 (profiles/).  A process-global switch, hence not the headline.
@@ -88,7 +94,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st", "eager-safe", "eager-ctypes"])
+    ap.add_argument("--mode", default="eager-safe", choices=["graph", "eager", "eager-st", "eager-safe", "eager-ctypes"])
     ap.add_argument("--timesteps", type=int, default=None, help="dynamic configs: timesteps per step in total (c4: 4)")
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--F", type=int, default=None)

@@ -303,6 +303,10 @@ static int read_count_blocking(const GeomView& g, const ImgView& im, hipStream_t
   return MGS_OK;
 }
 
+// The device counts instances in 32 unsigned bits; the C ABI (like the reference, rasterizer_impl.cu:282 `int num_rendered`)
+// hands them out as int32: saturate instead of wrapping negative (advisor r4; 2^31 instances would need > 80 GB of lists).
+static inline int32_t sat_i32(uint32_t v) { return v > 0x7fffffffu ? 0x7fffffff : (int32_t)v; }
+
 // status word layout: tag (16) | flags (16) | count (32)
 static inline bool status_arrived(uint64_t w, uint32_t tag) { return w != kStatusPending && (uint32_t)(w >> 48) == (tag & 0xffffu); }
 
@@ -420,7 +424,7 @@ int mgs_rasterize_forward_preprocess(const MgsRasterArgs* a, int32_t* radii, int
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R_ref;  // the reference's integer (>= the instances actually binned: a safe size for stage 2)
+  *num_rendered = sat_i32(R_ref);  // the reference's integer (>= the instances actually binned: a safe size for stage 2)
   return MGS_OK;
 }
 
@@ -479,7 +483,7 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
     if (rc) return rc;
     rc = check_prefiltered(fl);
     if (rc) return rc;
-    *num_rendered = (int32_t)R_ref;  // the reference's integer; the workspace has to hold the R instances actually binned
+    *num_rendered = sat_i32(R_ref);  // the reference's integer; the workspace has to hold the R instances actually binned
     if ((int)R > bs.cap) return MGS_NEED_CAPACITY;
     if (host_status) {  // (debug: the words are reported by the kernels as usual)
       volatile uint64_t* hs = host_status;
@@ -510,7 +514,7 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   }
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R_ref;
+  *num_rendered = sat_i32(R_ref);
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
   }
 }
@@ -524,10 +528,10 @@ static int forward_result_T(const MgsRasterArgs* a, int T, const uint64_t* host_
   const volatile uint64_t* hs = host_status;
   const uint64_t w0 = hs[0], w1 = hs[1];
   const bool a0 = status_arrived(w0, a->status_tag), a1 = status_arrived(w1, a->status_tag);
-  if (a0 && num_rendered) *num_rendered = (int32_t)(uint32_t)w0;
+  if (a0 && num_rendered) *num_rendered = sat_i32((uint32_t)w0);
   if (a0 && ref_rendered) {  // (stored before word 0: arrived if word 0 has)
     const uint64_t w2 = hs[2];
-    if (status_arrived(w2, a->status_tag)) *ref_rendered = (int32_t)(uint32_t)w2;
+    if (status_arrived(w2, a->status_tag)) *ref_rendered = sat_i32((uint32_t)w2);
   }
   if (a1 && chunks_used) *chunks_used = (int32_t)(uint32_t)w1;
   if (a0) {
@@ -775,7 +779,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   if (rc) return rc;
   rc = check_prefiltered(fl);
   if (rc) return rc;
-  *num_rendered = (int32_t)R_ref;
+  *num_rendered = sat_i32(R_ref);
   return (int)R > bs.cap ? MGS_NEED_CAPACITY : MGS_OK;
 }
 

@@ -31,7 +31,7 @@ print(c['name'], c['P'], f\"{c['W']}x{c['H']}\", 'renders/gpu', c['renders_per_s
       'ref_kernels', {k: v for k, v in (j.get('reference_kernels_same_gpu') or {}).items() if k in ('ms_per_step', 'this_library_over_reference_kernels', 'note')},
       'binding', j.get('host_binding'))
 "; }
-for W in golden quick tests host bench configs stats pmc trace extra; do
+for W in golden quick tests host pmc bench configs stats trace extra; do
   want "$@" || continue
   case $W in
   golden)
