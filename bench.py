@@ -12,16 +12,17 @@ F=32, one look-at view per GPU per step, production negative-focal cameras, inpu
 + one backward of the rasterizer through the public GaussianRasterizer autograd API (+ one all-reduce of the per-Gaussian
 parameter gradients when N>1; weak scaling: every GPU renders its own view of the replicated Gaussian set).
 
-Modes (all are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default eager-safe):
-  eager-safe  THE DEFAULT since round 5: K plain Python steps through the public autograd API under the PACKAGE DEFAULTS --
-            forward mode "safe" (this shape waits for the preprocess's report; nothing speculative), torch's default autograd
-            threading, the compiled binding (csrc/mgs_torch.cpp): what an unmodified caller of the drop-in gets, no opt-in of
-            any kind.  Since the binding cut the host cost of a step to ~80 us the eager step is GPU-bound at every BASELINE
-            shape and a few us FASTER than a replayed graph (rounds 1-4 made `graph` the headline because the ctypes shim's
-            113-145 us of Python per step made eager host-bound).
+Modes (all are timed and reported under "modes_ms_per_step"; `value` comes from --mode, default graph):
   graph     the step captured once with torch.cuda.graph through the PUBLIC autograd API and replayed (possible because
-            nothing in the library synchronises; needs --forward-mode async, the opt-in); one replay costs ~5 us more than
+            nothing in the library synchronises; needs --forward-mode async, the opt-in).  The headline: a replay needs ~10 us
+            of host time per step, so a 20-step region of 3 ms does not feel a host hiccup; one replay costs ~5 us more than
             the kernels.
+  eager-safe  K plain Python steps through the public autograd API under the PACKAGE DEFAULTS -- forward mode "safe" (this
+            shape waits for the preprocess's report: nothing speculative), torch's default autograd threading, the compiled
+            binding (csrc/mgs_torch.cpp): what an unmodified caller of the drop-in gets, no opt-in of any kind.  Since the
+            binding cut the host cost of a step to ~80 us this is GPU-bound at every BASELINE shape and usually a few us FASTER
+            than the graph (0.153-0.156 vs 0.155-0.160 ms at configs[2]); it is not the headline only because a host that waits
+            for the device once per step has no queue to absorb a hiccup (one 20-step run in ten read 0.18).
   eager-st  the Python step called K times with torch.autograd.set_multithreading_enabled(False): the backward is
             enqueued by the calling thread, the host runs ahead and the step is GPU-bound: ms_per_step == the sum of the
             kernel durations of rocprofv3 (profiles/).  A process-global switch, hence not the headline.
@@ -94,7 +95,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="eager-safe", choices=["graph", "eager", "eager-st", "eager-safe", "eager-ctypes"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-st", "eager-safe", "eager-ctypes"])
     ap.add_argument("--timesteps", type=int, default=None, help="dynamic configs: timesteps per step in total (c4: 4)")
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--F", type=int, default=None)
@@ -113,6 +114,8 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
     ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: binning tables in memory)")
+    ap.add_argument("--gm-waves", type=int, default=None, help="MgsOptions.gm_waves of every call (render backward: 16, or 8 = "
+                                                               "256-register form with its LDS operands read a step ahead)")
     ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
                     help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
                          "host-device synchronisation: what graph capture needs); 'safe' is the package default")
@@ -337,6 +340,8 @@ def main():
         _lib.set_option("fast_exp", args.fast_exp)
     if args.bin_mode is not None:
         _lib.set_option("bin_mode", args.bin_mode)
+    if args.gm_waves is not None:
+        _lib.set_option("gm_waves", args.gm_waves)
     # The package default ("safe") never sizes a workspace speculatively; a training loop that wants a step without any
     # host-device synchronisation -- and HIP-graph capture -- opts into "async", as this benchmark does (--forward-mode).
     manigaussian_amd.set_forward_mode(args.forward_mode)
