@@ -113,8 +113,8 @@ def _bin_bytes(L, cap, pool, W, H, F):
     return v
 
 
-def _worst_case(L, P, W, H, F, T):
-    budget = _state.safe_bytes()
+def _worst_case(L, P, W, H, F, T, dev=None):
+    budget = _state.safe_bytes(dev)
     k = (P, W, H, F, budget)
     v = _WORST.get(k)
     if v is None:
@@ -374,7 +374,7 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
                                bool(prefiltered), bool(debug), include_feature)
         key = (P, W, H, F, opts["tight_bins"])
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        cannot_overflow, cap_worst, pool_worst = _worst_case(L, P, W, H, F, T)
+        cannot_overflow, cap_worst, pool_worst = _worst_case(L, P, W, H, F, T, dev)
         guess = (cap_worst, pool_worst) if cannot_overflow else st.guess(key)  # worst case: no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and

@@ -74,7 +74,7 @@ def _push_config():
     e = _EXT[0]
     if e:
         e.configure({"safe": 0, "async": 1, "blocking": 2}[_MODE], {"repair": 0, "raise": 1}[_OVERFLOW],
-                    _HEADROOM["instances"], _HEADROOM["chunks"], _SAFE_BYTES)
+                    _HEADROOM["instances"], _HEADROOM["chunks"], -1 if _SAFE_BYTES is None else _SAFE_BYTES)
 
 
 def _drain_python_side(index):
@@ -143,21 +143,43 @@ _HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.5)),
 
 
 # A shape whose WORST-CASE workspace (every Gaussian in every tile, every chunk of every block visited) stays below this many
-# bytes is always given that workspace: its asynchronous forwards cannot overflow, need no warm-up call and no marks.
-# ManiGaussian's own shape (16 384 Gaussians, 128 x 128, 3 feature channels) needs 206 MB; configs[2] would need 4 GB and
-# goes by the marks instead.
-_SAFE_BYTES = int(float(os.environ.get("MGS_SAFE_WORKSPACE_MB", 1024)) * (1 << 20))
+# bytes is always given that workspace: its forwards cannot overflow, need no warm-up call, no marks and NO wait of any kind.
+# Default (round 5): 1/32 of the device's memory, at least 1 GB -- 9 GB on a 288 GB MI355X: ManiGaussian's own shape (16 384
+# Gaussians, 128 x 128, 3 feature channels) needs 206 MB, BASELINE configs[1] / [2] (100 000 Gaussians, 128 x 128) 4.0 GB per
+# forward in flight; the configs[4] shape (500 000 at 256 x 256: 85 GB) waits for the preprocess's report instead.  Rounds 2-4
+# used a fixed 1 GB: configs[2] then went by the marks, and under default options its host ran in lock step with the device
+# (one wait per forward; up to +12 % on a slow host, profiles/r05_bench_c2.json).  MGS_SAFE_WORKSPACE_MB / set_safe_workspace
+# fix the budget in megabytes (0: never allocate the worst case).
+_SAFE_BYTES = (int(float(os.environ["MGS_SAFE_WORKSPACE_MB"]) * (1 << 20)) if os.environ.get("MGS_SAFE_WORKSPACE_MB") else None)
+_AUTO_SAFE = {}  # device index -> max(1 GB, total memory / 32)
+SAFE_FRACTION = 32
 
 
-def set_safe_workspace(megabytes: float):
-    """Largest worst-case workspace (MB) the asynchronous forward simply allocates instead of guessing from earlier calls."""
+def set_safe_bytes(nbytes):
+    """The budget in bytes; None: the default (1/32 of the device's memory, at least 1 GB).  Returns the previous setting."""
     global _SAFE_BYTES
-    _SAFE_BYTES = int(float(megabytes) * (1 << 20))
+    old, _SAFE_BYTES = _SAFE_BYTES, (None if nbytes is None else int(nbytes))
     _push_config()
+    return old
 
 
-def safe_bytes() -> int:
-    return _SAFE_BYTES
+def set_safe_workspace(megabytes):
+    """Largest worst-case workspace (MB) a forward simply allocates instead of sizing it from earlier calls / the device's
+    report (None: the default, 1/32 of the device's memory)."""
+    set_safe_bytes(None if megabytes is None else int(float(megabytes) * (1 << 20)))
+
+
+def safe_bytes(dev=None) -> int:
+    if _SAFE_BYTES is not None:
+        return _SAFE_BYTES
+    idx = -1
+    if torch.cuda.is_available():
+        idx = dev.index if (dev is not None and getattr(dev, "index", None) is not None) else torch.cuda.current_device()
+    v = _AUTO_SAFE.get(idx)
+    if v is None:
+        total = torch.cuda.get_device_properties(idx).total_memory if idx >= 0 else 0
+        v = _AUTO_SAFE[idx] = max(1 << 30, total // SAFE_FRACTION)
+    return v
 
 
 def set_headroom(instances: float = None, chunks: float = None):

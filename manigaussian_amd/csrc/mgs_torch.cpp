@@ -55,7 +55,7 @@ struct Config {
   std::atomic<int> mode{MODE_SAFE};
   std::atomic<int> policy{POLICY_REPAIR};
   double head_inst = 1.5, head_chunks = 2.0;
-  int64_t safe_bytes = (int64_t)1 << 30;
+  int64_t safe_bytes = -1;  // < 0: per device, 1/32 of its memory and at least 1 GB (manigaussian_amd/_state.py safe_bytes)
   MgsOptions opt;       // per-call options every forward carries (manigaussian_amd._lib.DEFAULT_OPTIONS)
   std::mutex mu;
 };
@@ -145,6 +145,7 @@ struct DeviceState {
   std::deque<std::shared_ptr<PendingRec>> pending;
   std::mutex mu;
   bool python_side_built = false;  // manigaussian_amd._state.DeviceState of this device exists (see rasterize())
+  int64_t auto_safe_bytes = 0;     // the default worst-case-workspace budget of this device
 
   explicit DeviceState(int idx) : index(idx) {}
 
@@ -529,6 +530,14 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
     opt = C.opt; head_inst = C.head_inst; safe_bytes = C.safe_bytes;
   }
   (void)head_inst;
+  if (safe_bytes < 0) {  // the default budget: 1/32 of this device's memory, at least 1 GB
+    if (st.auto_safe_bytes == 0) {
+      size_t total = 0;
+      if (hipDeviceTotalMem(&total, di) != hipSuccess) { (void)hipGetLastError(); total = 0; }
+      st.auto_safe_bytes = std::max<int64_t>((int64_t)1 << 30, (int64_t)(total / 32));
+    }
+    safe_bytes = st.auto_safe_bytes;
+  }
   const Key key{0, (int32_t)P, (int32_t)W, (int32_t)H, (int32_t)F, opt.tight_bins};
   const int64_t T = ((W + 15) / 16) * ((H + 15) / 16);
   // worst case: every Gaussian in every tile, every chunk of every block visited

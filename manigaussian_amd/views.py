@@ -82,7 +82,7 @@ class _RasterizeViews(torch.autograd.Function):
             T1 = ((W + 15) // 16) * ((H + 15) // 16)
             cap_worst = V * P * T1  # every Gaussian in every tile of every view
             cannot_overflow = (0 < cap_worst < (1 << 30) and
-                               L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes())
+                               L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes(dev))
             if cannot_overflow:
                 guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))
             lazy = guess is not None and _state.lazy_allowed(cannot_overflow) and not s0.prefiltered

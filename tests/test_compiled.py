@@ -80,7 +80,7 @@ def _same(a, b):
 def test_compiled_path_is_what_runs_and_equals_the_ctypes_shim(mode, budget_mb):
     e = _ext()
     dev, d, rast, dC, dF = _setup(20000, 32)
-    old_mode, old_budget = mg.set_forward_mode(mode), _state.safe_bytes()
+    old_mode, old_budget = mg.set_forward_mode(mode), _state._SAFE_BYTES
     if budget_mb is not None:
         mg.set_safe_workspace(budget_mb)
     try:
@@ -99,15 +99,14 @@ def test_compiled_path_is_what_runs_and_equals_the_ctypes_shim(mode, budget_mb):
         _same(ref, got)
     finally:
         mg.set_forward_mode(old_mode)
-        _state._SAFE_BYTES = old_budget
-        _state._push_config()
+        _state.set_safe_bytes(old_budget)
 
 
 @pytest.mark.gpu
 def test_compiled_wait_path_retries_when_the_scene_outgrew_its_marks_and_never_returns_incomplete_images():
     e = _ext()
     dev, d, rast, dC, dF = _setup(15000, 3)
-    old_mode, old_budget = mg.set_forward_mode("safe"), _state.safe_bytes()
+    old_mode, old_budget = mg.set_forward_mode("safe"), _state._SAFE_BYTES
     mg.set_safe_workspace(0)
     try:
         with _C.use_compiled(False), util_forward_mode("blocking"):
@@ -132,8 +131,7 @@ def test_compiled_wait_path_retries_when_the_scene_outgrew_its_marks_and_never_r
         _same(ref, got2)
     finally:
         mg.set_forward_mode(old_mode)
-        _state._SAFE_BYTES = old_budget
-        _state._push_config()
+        _state.set_safe_bytes(old_budget)
 
 
 import contextlib

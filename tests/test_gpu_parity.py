@@ -205,13 +205,13 @@ def _marks_only():
     is small enough to be allocated outright: the tests of the marks / overflow machinery need it."""
     import manigaussian_amd as mg
     from manigaussian_amd import _state
-    old = _state.safe_bytes()
+    old = _state._SAFE_BYTES  # (None: the default)
     mg.set_safe_workspace(0)
     old_mode = mg.set_forward_mode("async")
     try:
         yield
     finally:
-        _state._SAFE_BYTES = old
+        _state.set_safe_bytes(old)
         mg.set_forward_mode(old_mode)
 
 
@@ -619,7 +619,7 @@ def test_default_mode_never_returns_incomplete_images_when_a_scene_grows():
             gs = torch.autograd.grad([c, f], list(leaves.values()), [dCd, dFd])
         return c, f, r, gs
 
-    old_budget = _state.safe_bytes()
+    old_budget = _state._SAFE_BYTES  # (None: the default)
     mg.set_safe_workspace(1)
     try:
         for batched in (False, True):
@@ -637,7 +637,7 @@ def test_default_mode_never_returns_incomplete_images_when_a_scene_grows():
                 for a, b in zip(g1, g0):
                     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12  # float atomics: order differs
     finally:
-        _state._SAFE_BYTES = old_budget
+        _state.set_safe_bytes(old_budget)
 
 
 def test_forward_backward_captured_into_a_hip_graph_replays_bit_identically():
