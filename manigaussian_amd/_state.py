@@ -146,7 +146,7 @@ _HEADROOM = {"instances": float(os.environ.get("MGS_HEADROOM_INSTANCES", 1.5)),
 # bytes is always given that workspace: its forwards cannot overflow, need no warm-up call, no marks and NO wait of any kind.
 # Default (round 5): 1/32 of the device's memory, at least 1 GB -- 9 GB on a 288 GB MI355X: ManiGaussian's own shape (16 384
 # Gaussians, 128 x 128, 3 feature channels) needs 206 MB, BASELINE configs[1] / [2] (100 000 Gaussians, 128 x 128) 4.0 GB per
-# forward in flight; the configs[4] shape (500 000 at 256 x 256: 85 GB) waits for the preprocess's report instead.  Rounds 2-4
+# forward in flight; the configs[4] shape (500 000 at 256 x 256: 79 GB) waits for the preprocess's report instead.  Rounds 2-4
 # used a fixed 1 GB: configs[2] then went by the marks, and under default options its host ran in lock step with the device
 # (one wait per forward; up to +12 % on a slow host, profiles/r05_bench_c2.json).  MGS_SAFE_WORKSPACE_MB / set_safe_workspace
 # fix the budget in megabytes (0: never allocate the worst case).
