@@ -114,8 +114,8 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
     ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: binning tables in memory)")
-    ap.add_argument("--gm-waves", type=int, default=None, help="MgsOptions.gm_waves of every call (render backward: 16, or 8 = "
-                                                               "256-register form with its LDS operands read a step ahead)")
+    ap.add_argument("--gm-waves", type=int, default=None, help="MgsOptions.gm_waves of every call (render backward: 12 = "
+                                                               "two pixels per step, the default; 16 / 8 = the one-pixel forms)")
     ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
                     help="manigaussian_amd.set_forward_mode: the bench opts into 'async' (speculative workspace sizing, no "
                          "host-device synchronisation: what graph capture needs); 'safe' is the package default")

@@ -60,7 +60,8 @@ typedef struct MgsOptions {
   int32_t bin_mode;     /* 1*: the bin scatter keeps its per-tile tables in LDS (up to 4096 tiles; more: as 0);
                            0: tables in memory, one atomic per instance -- any tile count.  Same sort + merge after either */
   int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048, 4096: for lists of >> 8192 per tile)  */
-  int32_t gm_waves;     /* 16*: waves per workgroup of the render backward (8 or 16)                               */
+  int32_t gm_waves;     /* 12*: render backward (one workgroup per CU): 12 waves x 168 registers, two pixels per step;
+                           16 / 8: the one-pixel-per-step forms of rounds 2-4 (16 x 128 / 8 x 256 registers)            */
   int32_t dbg;          /* 0*: diagnostics (256: phase timeline of the render forward, mgs_debug_read_trace; 512: test
                            hook -- the table-zeroing workgroup of the forward preprocess sleeps ~0.3 ms first)          */
   int32_t table_init;   /* 0*: the forward preprocess launch zeroes its own tile tables (workgroup 0 + a bounded hand-shake:

@@ -157,7 +157,7 @@ def check(rc: int, what: str):
 
 # Per-call tuning switches (MgsOptions): the C ABI has no process-wide option state; this dict is merely the DEFAULT the
 # Python shim copies into every call's MgsRasterArgs.opt (a forward's values travel to its backward in the autograd ctx).
-DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=1, seg=2048, gm_waves=16, dbg=0, table_init=0)
+DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=1, seg=2048, gm_waves=12, dbg=0, table_init=0)
 OPTIONS_VERSION = [0]  # bumped by set_option: callers that cache a filled MgsOptions key it on this
 
 

@@ -45,7 +45,7 @@ static Options options_of(const MgsRasterArgs* a) {
   Options o;
   if (a && a->opt.set) {
     o.tight_bins = a->opt.tight_bins; o.fast_exp = a->opt.fast_exp; o.exact_cull = a->opt.exact_cull;
-    o.bin_mode = a->opt.bin_mode ? 1 : 0; o.gm_waves = a->opt.gm_waves == 8 ? 8 : 16; o.dbg = a->opt.dbg;
+    o.bin_mode = a->opt.bin_mode ? 1 : 0; o.gm_waves = (a->opt.gm_waves == 8 || a->opt.gm_waves == 16) ? a->opt.gm_waves : 12; o.dbg = a->opt.dbg;
     o.seg = (a->opt.seg == 512 || a->opt.seg == 1024 || a->opt.seg == 4096) ? a->opt.seg : 2048;
     o.table_init = a->opt.table_init ? 1 : 0;
   }

@@ -199,7 +199,7 @@ struct Options {
   int exact_cull = 1;      // exact ellipse-vs-block cull on top of the bbox cull in the render forward
   int bin_mode = 1;        // 1: the bin scatter's tables in LDS (up to LDS_TILES tiles), 0: in memory (see mgs_binning.hip)
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
-  int gm_waves = 16;       // waves per workgroup of the render backward (8 or 16)
+  int gm_waves = 12;       // render backward at one workgroup per CU: 12 = 12 waves, two pixels per step; 16 / 8 = the one-pixel forms
   int dbg = 0;             // see RenderArgs::dbg
   int table_init = 0;      // 0: the preprocess launch zeroes its tables itself (workgroup 0 + hand-shake); 1: a zero-fill launch first
 };

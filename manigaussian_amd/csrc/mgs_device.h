@@ -110,6 +110,64 @@ __device__ __forceinline__ float half_incl_scan_mul(float v) {
       : "+&v"(r) : "v"(v));
   return r;
 }
+// Two independent inclusive scans in ONE asm block: the instructions of the two chains alternate, so each chain's DPP read finds
+// its source written two issue slots earlier (the other chain's instruction + one s_nop 0) -- 12 DPP + 4 s_nop for two scans
+// instead of 2 x (6 DPP + 4 s_nop 1).
+__device__ __forceinline__ void half_incl_scan_mul2(float& a, float& b) {
+  float ra = a, rb = b;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %3, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %0, %2, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %3, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %0, %2, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %3, %1 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+&v"(ra), "+&v"(rb) : "v"(a), "v"(b));
+  a = ra; b = rb;
+}
+__device__ __forceinline__ void half_incl_scan_add2(float& a, float& b) {
+  float ra = a, rb = b;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+&v"(ra), "+&v"(rb) : "v"(a), "v"(b));
+  a = ra; b = rb;
+}
+// two exclusive prefix products (see half_excl_scan_mul)
+__device__ __forceinline__ void half_excl_scan_mul2(float& a, float& b, int lane) {
+  float sa = dpp_keep<DPP_ROW_SHR1>(1.f, a), sb = dpp_keep<DPP_ROW_SHR1>(1.f, b);
+  const float pa = dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, a), pb = dpp_keep<DPP_ROW_BCAST15, 0xA>(1.f, b);
+  const bool first = (lane & 15) == 0 && (lane & 16);
+  sa = first ? pa : sa;
+  sb = first ? pb : sb;
+  half_incl_scan_mul2(sa, sb);
+  a = sa; b = sb;
+}
+
 // exclusive prefix product over the lanes of each 32-lane half (lane 0 / 32 get 1): the input shifted by one lane, scanned
 __device__ __forceinline__ float half_excl_scan_mul(float v, int lane) {
   float s = dpp_keep<DPP_ROW_SHR1>(1.f, v);                       // lane i <- v[i-1] inside a row

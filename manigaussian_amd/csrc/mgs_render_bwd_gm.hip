@@ -53,7 +53,13 @@ struct GmRec { float4 g0, g1; uint32_t id, pos; };
 // groups are full) and T_mid is the transmittance entering the second group.  Chunk c's record is
 // round_base[round c / NWF] + c % NWF with NWF = the forward's waves (RenderArgs::nwf).
 // NWF: waves of the forward that wrote the state (chunk records per round).  TWO: two workgroups share a CU.
-template <int F, bool FAST, int NW, int NWF_, bool TWO>
+// PAIR (round 5, the default form at one workgroup per CU): a lane walks its pixels TWO AT A TIME (steps 2j, 2j + 1: neighbours
+// in a pixel row) -- two independent dependency chains per lane, the arithmetic and the exact exp's multiply-adds in packed fp32
+// (v_pk_*), the four DPP scans of a double step as two interleaved pairs (each chain's wait states are the other's issue slots):
+// 148 vector issue slots per double step against 2 x 87, 14 s_nop against 30.  It needs 167 registers, hence 12 waves per
+// workgroup (3 per SIMD: 168 registers each) instead of 16 x 128; a block's chunks 12 .. 15 (rare) go to waves 0 .. 3 in a second
+// pass.  configs[2]: 55.3 -> 50.4 us; gradients equal the one-pixel form's to 1e-6 of the tensor max (another summation order).
+template <int F, bool FAST, int NW, int NWF_, bool TWO, bool PAIR = false>
 __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs r, const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ round_base,
                                                           const uint32_t* __restrict__ last_chunk,
@@ -364,6 +370,69 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
           Dt = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? dLT[F + 2][32 * u + n] : 0.f, bop[FH + 1], Dt, 0, 0, 0);
         }
         const float pyu = by0 + (float)(4 * u);
+        if constexpr (PAIR) {
+          f32x2 p_mx = {0.f, 0.f}, p_my = {0.f, 0.f}, p_cx = {0.f, 0.f}, p_cy = {0.f, 0.f}, p_cz = {0.f, 0.f}, p_op = {0.f, 0.f};
+          f32x2 p_r = {0.f, 0.f}, p_g = {0.f, 0.f}, p_b = {0.f, 0.f};
+#pragma unroll 1
+          for (int j = 0; j < 8; j++) {  // steps 2j, 2j + 1: pixels (x, x + 1) of one row of my half tile
+            const int rr = 2 * j;
+            const int bit = (rr & 3) + 8 * (rr >> 2);
+            if (((lmu >> bit) & 0x33u) == 0u) continue;  // all four pixels of the double step (two per half-wave) dead in this group
+            const int pp = 32 * u + bit + 4 * h;         // my first pixel; the second is pp + 1
+            const float4 s0 = pd[w][pp], s1 = pd[w][pp + 1];
+            const f32x2 Tg = (g == 0) ? f32x2{s0.x, s1.x} : f32x2{s0.w, s1.w};
+            const float dx0 = ex - (bx0 + (float)((rr & 3) + 4 * h));
+            const f32x2 dx = {dx0, dx0 - 1.0f};
+            const float dy = ey - (pyu + (float)(rr >> 2));
+            const f32x2 power = gauss_power2(cx, cy, cz, dx, dy);
+            const f32x2 G = exp2_<FAST>(power);
+            const f32x2 alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+            const bool act0 = pos <= __float_as_uint(s0.z) && !(power.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
+            const bool act1 = pos <= __float_as_uint(s1.z) && !(power.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
+            const f32x2 om = {act0 ? 1.0f - alpha.x : 1.0f, act1 ? 1.0f - alpha.y : 1.0f};
+            float e0 = om.x, e1 = om.y;
+            half_excl_scan_mul2(e0, e1, lane);
+            const f32x2 T = Tg * f32x2{e0, e1};                        // transmittance before my Gaussian, both pixels
+            const f32x2 waT = alpha * T;
+            const f32x2 wa = {act0 ? waT.x : 0.f, act1 ? waT.y : 0.f};
+            const f32x2 D = {Dt[rr], Dt[rr + 1]};
+            const f32x2 Dw = D * wa;
+            float q0 = Dw.x, q1 = Dw.y;
+            half_incl_scan_add2(q0, q1);
+            const f32x2 tot = {half_last(q0, lane), half_last(q1, lane)};
+            const f32x2 sy = {s0.y, s1.y};
+            const f32x2 S = (tot - f32x2{q0, q1}) + sy;
+            if (g > 0 && n == 0) { pd[w][pp].y = sy.x + tot.x; pd[w][pp + 1].y = sy.y + tot.y; }
+            const f32x2 rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+            const f32x2 dLa_ = D * T - S * rom;
+            const f32x2 dLa = {act0 ? dLa_.x : 0.f, act1 ? dLa_.y : 0.f};
+            const f32x2 dLG = op * dLa;
+            const f32x2 gdx = G * dx, gdy = G * dy;
+            p_mx += dLG * (-gdx * cx - gdy * cy);
+            p_my += dLG * (-gdy * cz - gdx * cy);
+            p_cx += gdx * dx * dLG;
+            p_cy += gdx * dy * dLG;
+            p_cz += gdy * dy * dLG;
+            p_op += G * dLa;
+            touched = (act0 || act1) ? 1.0f : touched;
+            p_r += wa * f32x2{dLT[F][pp], dLT[F][pp + 1]};
+            p_g += wa * f32x2{dLT[F + 1][pp], dLT[F + 1][pp + 1]};
+            p_b += wa * f32x2{dLT[F + 2][pp], dLT[F + 2][pp + 1]};
+            if constexpr (NCT > 0) {
+              if (use_feat) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) {
+                  const bool okc = 32 * ct + n < KCH;
+                  const float a0 = okc ? dLT[32 * ct + n][pp] : 0.f, a1 = okc ? dLT[32 * ct + n][pp + 1] : 0.f;
+                  Cf[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wa.x, Cf[ct], 0, 0, 0);
+                  Cf[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wa.y, Cf[ct], 0, 0, 0);
+                }
+              }
+            }
+          }
+          a_mx += p_mx.x + p_mx.y; a_my += p_my.x + p_my.y; a_cx += p_cx.x + p_cx.y; a_cy += p_cy.x + p_cy.y;
+          a_cz += p_cz.x + p_cz.y; a_op += p_op.x + p_op.y; a_r += p_r.x + p_r.y; a_g += p_g.x + p_g.y; a_b += p_b.x + p_b.y;
+        } else
 #pragma unroll 1
         for (int rr = 0; rr < 16; rr++) {  // rolled: one pixel step's worth of registers (Dt[rr]: uniform index)
           if (((lmu >> ((rr & 3) + 8 * (rr >> 2))) & 0x11u) == 0u) continue;  // both pixels of the step dead in this group
@@ -372,7 +441,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
           const float Tg = (g == 0) ? st.x : st.w;                   // transmittance entering this group
           const float dx = ex - (bx0 + (float)((rr & 3) + 4 * h));
           const float dy = ey - (pyu + (float)(rr >> 2));
-          const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+          const float power = gauss_power(cx, cy, cz, dx, dy);
           const float G = gm_exp<FAST>(power);
           const float alpha = fminf(0.99f, op * G);
           const bool act = pos <= __float_as_uint(st.z) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
@@ -475,19 +544,21 @@ static hipError_t gm_F(const RenderArgs& r, const ImgView& im, const ChunkView& 
                        float* acc8, float* dcol, float* dfeat, hipStream_t s) {
   const int T = r.tiles_x * r.tiles_y;
   const int grid = ((T + 7) / 8) * 32;
-#define MGS_GM(FAST, NW, NWF, TWO)                                                                                    \
-  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, NW, NWF, TWO>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges,            \
+#define MGS_GM(FAST, NW, NWF, TWO, PAIR)                                                                              \
+  hipLaunchKernelGGL((gm_bwd_kernel<F, FAST, NW, NWF, TWO, PAIR>), dim3(grid), dim3(NW * 64), 0, s, r, im.ranges,      \
                      cv.round_base, cv.last_chunk, cv.T_end, cv.last_pos, cv.partial, cv.q, im.final_T, dc, df, acc8, \
                      dcol, dfeat, cv.T_mid, cv.surv, cv.surv_stride, cv.nsurv)
-#define MGS_GMF(NW, NWF, TWO) do { if (r.fast_exp) MGS_GM(true, NW, NWF, TWO); else MGS_GM(false, NW, NWF, TWO); } while (0)
+#define MGS_GMF(NW, NWF, TWO, PAIR) do { if (r.fast_exp) MGS_GM(true, NW, NWF, TWO, PAIR); else MGS_GM(false, NW, NWF, TWO, PAIR); } while (0)
   if constexpr (F > 32) {
-    MGS_GMF(8, 8, false);                        // wide rows: 8 waves x 256 registers (the forward ran 8 waves as well)
+    MGS_GMF(8, 8, false, false);                 // wide rows: 8 waves x 256 registers (the forward ran 8 waves as well)
   } else if (r.nwf == 8) {
-    MGS_GMF(8, 8, true);                         // more blocks than CUs: two 8-wave workgroups per CU
+    MGS_GMF(8, 8, true, false);                  // more blocks than CUs: two 8-wave workgroups per CU
   } else if (r.gm_waves == 8) {
-    MGS_GMF(8, 16, false);                       // option: 8 waves x 256 registers behind a 16-wave forward
+    MGS_GMF(8, 16, false, false);                // option: 8 waves x 256 registers behind a 16-wave forward
+  } else if (r.gm_waves == 16) {
+    MGS_GMF(16, 16, false, false);               // option: the rounds 2-4 form, 16 waves x 128 registers, one pixel per step
   } else {
-    MGS_GMF(16, 16, false);
+    MGS_GMF(12, 16, false, true);                // default: 12 waves x 168 registers, two pixels per step
   }
 #undef MGS_GMF
 #undef MGS_GM

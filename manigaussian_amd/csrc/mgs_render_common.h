@@ -19,6 +19,42 @@ __device__ __forceinline__ float exp_ocml_unclamped(float x) {
   const float a = (ph - e) + pl;
   return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
 }
+// The same for two arguments at once: the multiply-adds as packed fp32 operations (v_pk_mul / v_pk_fma / v_pk_add: IEEE, the
+// same roundings as the scalar forms); rint, exp2 and ldexp per component.  mgs_selftest compares it with expf bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_ocml_unclamped2(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 c = {0x1.715476p+0f, 0x1.715476p+0f}, c2 = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+  const f32x2 ph = x * c;
+  f32x2 pl = __builtin_elementwise_fma(x, c, -ph);
+  const f32x2 e = {__builtin_rintf(ph.x), __builtin_rintf(ph.y)};
+  pl = __builtin_elementwise_fma(x, c2, pl);
+  const f32x2 a = (ph - e) + pl;
+  return f32x2{__builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)e.x),
+               __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)e.y)};
+}
+// The exponent of one (pixel, Gaussian) pair, -1/2 (cx dx^2 + cz dy^2) - cy dx dy (forward.cu:345-347, backward.cu:456-458).
+// EVERY kernel that takes the pair's two decisions (power > 0 -> skip, alpha < 1/255 -> skip) evaluates it through these two
+// functions: the forward and every form of the backward must round it identically, or a pair within an ulp of a threshold is
+// blended by one and skipped by the other (the transmittances and suffix sums of the backward are then those of another
+// blend).  Written with explicit operations and contraction off: left to the compiler, the scalar and the packed expression
+// are fused differently (mul + sub against one fma for the last step).  mgs_selftest compares the two forms bit for bit.
+__device__ __forceinline__ float gauss_power(float cx, float cy, float cz, float dx, float dy) {
+#pragma clang fp contract(off)
+  const float t = __builtin_fmaf(cx * dx, dx, (cz * dy) * dy);
+  return __builtin_fmaf(-0.5f, t, -((cy * dx) * dy));
+}
+__device__ __forceinline__ f32x2 gauss_power2(float cx, float cy, float cz, f32x2 dx, float dy) {
+#pragma clang fp contract(off)
+  const float yy = (cz * dy) * dy;
+  const f32x2 t = __builtin_elementwise_fma(cx * dx, dx, f32x2{yy, yy});
+  return __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, t, -((cy * dx) * dy));
+}
+template <bool FAST>
+__device__ __forceinline__ f32x2 exp2_(f32x2 x) {
+  if constexpr (FAST) return f32x2{__expf(x.x), __expf(x.y)};
+  else return exp_ocml_unclamped2(x);
+}
 template <bool FAST>
 __device__ __forceinline__ float exp_(float x) {
   if constexpr (FAST) return __expf(x);

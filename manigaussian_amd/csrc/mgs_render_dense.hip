@@ -198,7 +198,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       const float4 A = recA[w][2 * s + k];
       const float2 B = recB[w][2 * s + k];
       const float dx = A.x - pq.pxf, dy = A.y - pq.pyf;
-      const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+      const float power = gauss_power(A.z, A.w, B.x, dx, dy);
       const float alpha = fminf(0.99f, B.y * exp_<FAST>(power));
       return ((power > 0.0f) || (alpha < 1.0f / 255.0f)) ? 0.f : alpha;
     };

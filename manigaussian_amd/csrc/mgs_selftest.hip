@@ -47,6 +47,17 @@ __global__ void selftest_kernel(int* result) {
     for (int i = 0; i < n; i++) em *= (((lane & 32) + i) % 3 == 0) ? 2.f : 1.f;
     if (half_excl_scan_mul(m, lane) != em) bad |= 1 << 21;
     if (half_last((float)lane, lane) != ((lane & 32) ? 63.f : 31.f)) bad |= 1 << 22;
+    // the two-at-a-time forms of the render backward's double pixel step: each chain equals its single scan
+    const float a2 = (float)((lane * 3) % 5 + 1), m2 = (lane % 4 == 1) ? 2.f : 1.f;
+    float ea2 = 0.f, em2 = 1.f;
+    for (int i = 0; i <= n; i++) ea2 += (float)((((lane & 32) + i) * 3) % 5 + 1);
+    for (int i = 0; i < n; i++) em2 *= (((lane & 32) + i) % 4 == 1) ? 2.f : 1.f;
+    float sa = a, sb = a2;
+    half_incl_scan_add2(sa, sb);
+    if (sa != ea || sb != ea2) bad |= 1 << 26;
+    float pa = m, pb = m2;
+    half_excl_scan_mul2(pa, pb, lane);
+    if (pa != em || pb != em2) bad |= 1 << 27;
   }
   {  // the fp32 MFMA the render kernels use is exact fp32: C = A (32x2) * B (2x32) with small integers
     using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -69,6 +80,21 @@ __global__ void selftest_kernel(int* result) {
     }
     const float xp = (float)lane * 1.37f;
     if (__float_as_uint(exp_ocml_unclamped(xp)) != __float_as_uint(expf(xp))) bad |= 1 << 25;
+    // ... and its two-wide form (packed multiply-adds: the same roundings)
+    for (int i = 0; i < 1024; i++) {
+      const float x0 = -((float)(lane * 1024 + i) * 1.5258789e-3f + (float)i * 2.3841858e-7f), x1 = x0 * 0.37f - 0.011f;
+      const f32x2 e2 = exp_ocml_unclamped2(f32x2{x0, x1});
+      if (__float_as_uint(e2.x) != __float_as_uint(expf(x0)) || __float_as_uint(e2.y) != __float_as_uint(expf(x1))) bad |= 1 << 28;
+    }
+    // the pair exponent: its packed form rounds like its scalar form (conic and offsets of the sizes the renderer sees)
+    for (int i = 0; i < 1024; i++) {
+      const float cx = 0.01f + (float)((lane * 37 + i * 11) % 997) * 3.1e-3f, cz = 0.02f + (float)((lane * 53 + i * 7) % 991) * 2.7e-3f;
+      const float cy = ((float)((lane * 29 + i * 13) % 983) - 491.f) * 1.9e-3f;
+      const float dx0 = ((float)((lane * 17 + i * 5) % 1021) - 510.f) * 0.0313f, dy = ((float)((lane * 3 + i * 19) % 1019) - 509.f) * 0.0291f;
+      const f32x2 p2 = gauss_power2(cx, cy, cz, f32x2{dx0, dx0 - 1.0f}, dy);
+      if (__float_as_uint(p2.x) != __float_as_uint(gauss_power(cx, cy, cz, dx0, dy)) ||
+          __float_as_uint(p2.y) != __float_as_uint(gauss_power(cx, cy, cz, dx0 - 1.0f, dy))) bad |= 1 << 29;
+    }
   }
   if (bad) atomicOr(result, bad);
 }

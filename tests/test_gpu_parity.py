@@ -152,11 +152,12 @@ def test_parity_with_oracle(name, tight):
     _check(CASES[name], tight_bins=tight)
 
 
-_DEFAULTS = dict(gm_waves=16, bin_mode=1, seg=2048, exact_cull=1, fast_exp=0, tight_bins=1)
+_DEFAULTS = dict(gm_waves=12, bin_mode=1, seg=2048, exact_cull=1, fast_exp=0, tight_bins=1)
 VARIANTS = {
     "binning_tables_in_memory": dict(bin_mode=0),
     "segments_512": dict(seg=512), "segments_1024": dict(seg=1024), "segments_4096": dict(seg=4096),
     "backward_8_waves": dict(gm_waves=8),
+    "backward_16_waves_one_pixel_per_step": dict(gm_waves=16),
     "v_exp_f32_bbox_cull": dict(fast_exp=1, exact_cull=0), "v_exp_f32": dict(fast_exp=1),
 }
 
@@ -172,6 +173,33 @@ def test_kernel_variants_agree_with_oracle(name):
     finally:
         for k, v in _DEFAULTS.items():
             _lib.set_option(k, v)
+
+
+@pytest.mark.parametrize("P,F,view", [(20000, 32, 0), (20000, 32, 5), (30000, 3, 2), (100000, 32, 1)])
+def test_backward_forms_take_the_forward_s_decisions(P, F, view):
+    """The three forms of the render backward (12 waves / two pixels per step, 16 and 8 waves / one pixel per step) evaluate
+    the pair exponent through the same function as the forward (mgs_render_common.h gauss_power / gauss_power2), so they skip
+    exactly the pairs the forward skipped: their gradients differ by summation order only (<= 1e-5 of the tensor's max; one pair
+    decided differently shows as ~1e-3).  Round 5 regression: the packed form once multiplied (cy dy) dx instead of (cy dx) dy,
+    one ulp apart, and blended one pair of view 0 of the first scene that the forward had skipped -- 1.4e-3 of the max on one
+    Gaussian, inside the 1e-3-of-max-away-from-fragile-pairs contract of every test against the oracles, caught only by
+    test_view_batch_equals_per_view_calls."""
+    sc = syn.make_scene(P, F=F, M=4, seed=2)
+    cam = syn.circle_cameras(8, 128, 128, negative_focal=True)[view]
+    g = torch.Generator().manual_seed(4 + view)
+    dC, dF = torch.randn(3, 128, 128, generator=g), torch.randn(F, 128, 128, generator=g)
+    res = {}
+    try:
+        for gw in (16, 12, 8):
+            _lib.set_option("gm_waves", gw)
+            res[gw] = util.run_hip(sc, cam, dC, dF, 1, True, (0.1, 0.2, 0.3))
+    finally:
+        _lib.set_option("gm_waves", _DEFAULTS["gm_waves"])
+    for gw in (12, 8):
+        assert torch.equal(res[gw][0], res[16][0]) and torch.equal(res[gw][1], res[16][1])
+        for k, ref in res[16][3].items():
+            d = (res[gw][3][k] - ref).abs().max().item()
+            assert d <= 1e-5 * ref.abs().max().item() + 1e-9, (gw, k, d, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("seg,P", [(512, 520), (512, 700), (512, 1030), (512, 1300), (512, 1540), (512, 2100), (512, 2570),
