@@ -50,6 +50,12 @@ __device__ __forceinline__ f32x2 gauss_power2(float cx, float cy, float cz, f32x
   const f32x2 t = __builtin_elementwise_fma(cx * dx, dx, f32x2{yy, yy});
   return __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, t, -((cy * dx) * dy));
 }
+// ... and with two Gaussians (conics) as well as two offsets: the forward's double steps
+__device__ __forceinline__ f32x2 gauss_power2v(f32x2 cx, f32x2 cy, f32x2 cz, f32x2 dx, f32x2 dy) {
+#pragma clang fp contract(off)
+  const f32x2 t = __builtin_elementwise_fma(cx * dx, dx, (cz * dy) * dy);
+  return __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, t, -((cy * dx) * dy));
+}
 template <bool FAST>
 __device__ __forceinline__ f32x2 exp2_(f32x2 x) {
   if constexpr (FAST) return f32x2{__expf(x.x), __expf(x.y)};

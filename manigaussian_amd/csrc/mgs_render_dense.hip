@@ -73,8 +73,12 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   __shared__ float trs[MF ? NW * TRR * TRS : 1];      // per wave: [channel][pixel] hand-over of the MFMA accumulators; after the
                                              // rounds it still holds the wave's LAST chunk: the final sum reads that one here
   __shared__ uint32_t lastcc[NW];            // ... its dense chunk index (0xffffffff: the wave blended nothing)
-  __shared__ float4 recA[NW][CHS];           // per wave, the chunk under evaluation: {x, y, conic.x, conic.y}
-  __shared__ float2 recB[NW][CHS];           //                                       {conic.z, opacity (0: no entry)}
+  // per wave, the chunk under evaluation, laid out for phase A's DOUBLE steps: the lanes of parity k evaluate entries
+  // ea = 4 j + k and eb = ea + 2 in double step j, and (j, k) owns 12 consecutive floats {x_a, x_b, y_a, y_b | cx_a, cx_b, cy_a,
+  // cy_b | cz_a, cz_b, o_a, o_b} (conic = (cx, cy, cz); opacity 0: no entry) -- three 16-byte reads whose register pairs are
+  // the operands of the packed fp32 arithmetic as they arrive (the compiler's own pairing of two steps spent 8 of its 57
+  // instructions per double step on v_mov shuffles)
+  __shared__ float4 recP[NW][CHS / 4 * 2 * 3];
   __shared__ float4 rowq[NW][NS][CHS];       // per wave and chunk slot, for the blend: {r, g, b, Gaussian (bits)}
   __shared__ float rowf[NVF > 0 ? NW * NS * CHS * NVF : 1];  // ... and the feature row when it is blended on the VALU
   __shared__ float Tp[2][NW][64];            // per-chunk transmittance products [chunk of the round][pixel], double buffered
@@ -194,17 +198,25 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     // ---- phase A: my pair's chunks pr and pr + NP: stage the records, alpha of (my pixel, my entries), the products ----
     // alpha of entry 2s + k for pixel pixq with the reference's two skip tests folded in (forward.cu:345-356; 0 = skipped:
     // 1 - 0 = 1 exactly, a skipped entry leaves every product alone), from the records staged in this wave's LDS
-    auto alpha_of = [&](int s) -> float {
-      const float4 A = recA[w][2 * s + k];
-      const float2 B = recB[w][2 * s + k];
-      const float dx = A.x - pq.pxf, dy = A.y - pq.pyf;
-      const float power = gauss_power(A.z, A.w, B.x, dx, dy);
-      const float alpha = fminf(0.99f, B.y * exp_<FAST>(power));
-      return ((power > 0.0f) || (alpha < 1.0f / 255.0f)) ? 0.f : alpha;
+    // (two at a time: steps 2 j and 2 j + 1, i.e. entries 4 j + k and 4 j + 2 + k, in packed fp32 -- the same roundings as the
+    //  scalar form, mgs_selftest bits 28 / 29)
+    struct Rec3 { float4 XY, CC, ZO; };
+    auto rec3_of = [&](int j) -> Rec3 {
+      return Rec3{recP[w][(2 * j + k) * 3], recP[w][(2 * j + k) * 3 + 1], recP[w][(2 * j + k) * 3 + 2]};
     };
+    auto alpha2_rec = [&](const Rec3& R) -> f32x2 {
+      const float4 XY = R.XY, CC = R.CC, ZO = R.ZO;
+      const f32x2 dx = f32x2{XY.x, XY.y} - pq.pxf, dy = f32x2{XY.z, XY.w} - pq.pyf;
+      const f32x2 power = gauss_power2v(f32x2{CC.x, CC.y}, f32x2{CC.z, CC.w}, f32x2{ZO.x, ZO.y}, dx, dy);
+      const f32x2 G = exp2_<FAST>(power);
+      const f32x2 oG = f32x2{ZO.z, ZO.w} * G;
+      const float a0 = fminf(0.99f, oG.x), a1 = fminf(0.99f, oG.y);
+      return f32x2{((power.x > 0.0f) || (a0 < 1.0f / 255.0f)) ? 0.f : a0, ((power.y > 0.0f) || (a1 < 1.0f / 255.0f)) ? 0.f : a1};
+    };
+    auto alpha2_of = [&](int j) -> f32x2 { return alpha2_rec(rec3_of(j)); };
     float al[NSTEP];          // the alphas of my FIRST chunk stay in registers: its blend evaluates no exp.  (The second
                               // chunk of a round -- blocks with more than NW/2 live chunks -- is staged last, so its records
-                              // are still in recA / recB when it is blended: its alphas are evaluated again there.)
+                              // are still in recP when it is blended: its alphas are evaluated again there.)
     uint32_t nmy[NS];         // survivors of my chunks
 #pragma unroll
     for (int q = 0; q < NS; q++) {
@@ -238,9 +250,12 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
             }
           }
         }
-        wave_lds_sync();  // this wave's readers of recA / recB (the previous chunk's phase A) are done
-        recA[w][lane] = g0;
-        recB[w][lane] = make_float2(g1.x, valid ? g1.y : 0.f);  // opacity 0 => alpha 0 => skipped: no bounds test per step
+        wave_lds_sync();  // this wave's readers of recP (the previous chunk's phase A) are done
+        {
+          float* rp = reinterpret_cast<float*>(&recP[w][0]) + (((lane >> 2) * 2 + (lane & 1)) * 12 + ((lane >> 1) & 1));
+          rp[0] = g0.x; rp[2] = g0.y; rp[4] = g0.z; rp[6] = g0.w; rp[8] = g1.x;
+          rp[10] = valid ? g1.y : 0.f;  // opacity 0 => alpha 0 => skipped: no bounds test per step
+        }
         rowq[w][q][lane] = rq;
         if constexpr (NVF > 0) {
 #pragma unroll
@@ -250,12 +265,17 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
         if (q == 0) MGS_TRACE(3 + 8 * round);
         // straight-line: no per-step branch (an entry past the chunk's end has opacity 0 => alpha 0), so that the
         // compiler batches the LDS reads of several steps ahead of their use
+        f32x2 tp2 = {1.0f, 1.0f};
+        Rec3 Rn = rec3_of(0);  // the records of a double step are read one double step ahead of their use
 #pragma unroll
-        for (int s = 0; s < NSTEP; s++) {
-          const float a = alpha_of(s);
-          if (q == 0) al[s] = a;
-          tp = tp * (1.0f - a);
+        for (int j = 0; j < NSTEP / 2; j++) {
+          const Rec3 Rc = Rn;
+          if (j + 1 < NSTEP / 2) Rn = rec3_of(j + 1);
+          const f32x2 a2 = alpha2_rec(Rc);
+          if (q == 0) { al[2 * j] = a2.x; al[2 * j + 1] = a2.y; }
+          tp2 = tp2 * (1.0f - a2);
         }
+        tp = tp2.x * tp2.y;
         float t0 = tp, t1 = tp;
         swap32(t0, t1);       // t0: the even entries' product, t1: the odd entries', in both lanes of the pixel
         tp = t0 * t1;
@@ -334,10 +354,12 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
           stop = stop || (uint32_t)(2 * g * GS) >= n_my || ballot(alive != 0.f) == 0;
           __builtin_amdgcn_sched_barrier(0);
           if (!stop) {
+            f32x2 a2q = {0.f, 0.f};  // the second chunk's alphas of a double step (evaluated at its even step)
 #pragma unroll
             for (int u4 = 0; u4 < GS; u4++) {
               const int s = g * GS + u4;
-              float a0 = (q == 0) ? al[s] : alpha_of(s), a1 = a0;
+              if (q != 0 && (u4 & 1) == 0) a2q = alpha2_of(s >> 1);
+              float a0 = (q == 0) ? al[s] : ((u4 & 1) ? a2q.y : a2q.x), a1 = a0;
               swap32(a0, a1);  // a0 = alpha of entry 2s, a1 = alpha of entry 2s + 1 for my pixel, in both of its lanes
               // two entries of the reference's per-pixel walk (forward.cu:357-380).  A live pixel always has T >= 1e-4 (it
               // entered so, and a blend only happens when the new T stays above), hence alpha == 0 (a skipped entry) can

@@ -94,6 +94,9 @@ __global__ void selftest_kernel(int* result) {
       const f32x2 p2 = gauss_power2(cx, cy, cz, f32x2{dx0, dx0 - 1.0f}, dy);
       if (__float_as_uint(p2.x) != __float_as_uint(gauss_power(cx, cy, cz, dx0, dy)) ||
           __float_as_uint(p2.y) != __float_as_uint(gauss_power(cx, cy, cz, dx0 - 1.0f, dy))) bad |= 1 << 29;
+      const f32x2 p3 = gauss_power2v(f32x2{cx, cz}, f32x2{cy, -cy}, f32x2{cz, cx}, f32x2{dx0, dy}, f32x2{dy, dx0});
+      if (__float_as_uint(p3.x) != __float_as_uint(gauss_power(cx, cy, cz, dx0, dy)) ||
+          __float_as_uint(p3.y) != __float_as_uint(gauss_power(cz, -cy, cx, dy, dx0))) bad |= 1 << 29;
     }
   }
   if (bad) atomicOr(result, bad);
