@@ -78,7 +78,8 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   // cy_b | cz_a, cz_b, o_a, o_b} (conic = (cx, cy, cz); opacity 0: no entry) -- three 16-byte reads whose register pairs are
   // the operands of the packed fp32 arithmetic as they arrive (the compiler's own pairing of two steps spent 8 of its 57
   // instructions per double step on v_mov shuffles)
-  __shared__ float4 recP[NW][CHS / 4 * 2 * 3];
+  __shared__ float4 recP[NW][CHS / 4 * 2 * 3];  // indexed by the chunk's number in the round (both waves of a pair read one copy)
+  __shared__ uint32_t sid[NW * CHS];         // round 0: the survivors' instance ids, in list order (written by the fill)
   __shared__ float4 rowq[NW][NS][CHS];       // per wave and chunk slot, for the blend: {r, g, b, Gaussian (bits)}
   __shared__ float rowf[NVF > 0 ? NW * NS * CHS * NVF : 1];  // ... and the feature row when it is blended on the VALU
   __shared__ float Tp[2][NW][64];            // per-chunk transmittance products [chunk of the round][pixel], double buffered
@@ -147,8 +148,8 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     //      survivors go, in list order, to this block's list in memory (read back below and by the backward) ----
     while (qtail - qhead < ROUND && next < rng.y) {
       uint32_t idd[FILLK], rk[FILLK];
+      float4 a0[FILLK], a1[FILLK];
       {
-        float4 a0[FILLK], a1[FILLK];
 #pragma unroll
         for (int kf = 0; kf < FILLK; kf++) {
           const uint32_t e = next + (uint32_t)kf * FSTEP + (uint32_t)tid;
@@ -175,7 +176,20 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
       for (int kf = 0; kf < FILLK; kf++) {
         const uint32_t base = bcast_lane_u32(incl - v, kf * NW + w);
-        if (rk[kf] != 0xffffffffu) my_surv[qtail + base + rk[kf]] = idd[kf];
+        if (rk[kf] != 0xffffffffu) {
+          const uint32_t n = qtail + base + rk[kf];
+          my_surv[n] = idd[kf];
+          // Round 0 (qhead = 0): the survivor's record goes straight into the LDS buffer of its chunk, in phase A's layout, and
+          // its id beside it -- phase A used to fetch both again through memory (list -> record: two dependent round trips
+          // of ~4 k cycles per chunk slot, on every block's critical path).  Later rounds (18 of 256 blocks at configs[2]) and
+          // survivors beyond the round's window take the old way.
+          if (round == 0 && n < ROUND) {
+            const uint32_t e = n & (CHS - 1);
+            float* rp = reinterpret_cast<float*>(&recP[n / CHS][0]) + (((e >> 2) * 2 + (e & 1)) * 12 + ((e >> 1) & 1));
+            rp[0] = a0[kf].x; rp[2] = a0[kf].y; rp[4] = a0[kf].z; rp[6] = a0[kf].w; rp[8] = a1[kf].x; rp[10] = a1[kf].y;
+            sid[n] = idd[kf];
+          }
+        }
       }
       qtail += total;
       next += FILLK * FSTEP;
@@ -201,8 +215,8 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
     // (two at a time: steps 2 j and 2 j + 1, i.e. entries 4 j + k and 4 j + 2 + k, in packed fp32 -- the same roundings as the
     //  scalar form, mgs_selftest bits 28 / 29)
     struct Rec3 { float4 XY, CC, ZO; };
-    auto rec3_of = [&](int j) -> Rec3 {
-      return Rec3{recP[w][(2 * j + k) * 3], recP[w][(2 * j + k) * 3 + 1], recP[w][(2 * j + k) * 3 + 2]};
+    auto rec3_of = [&](uint32_t buf, int j) -> Rec3 {
+      return Rec3{recP[buf][(2 * j + k) * 3], recP[buf][(2 * j + k) * 3 + 1], recP[buf][(2 * j + k) * 3 + 2]};
     };
     auto alpha2_rec = [&](const Rec3& R) -> f32x2 {
       const float4 XY = R.XY, CC = R.CC, ZO = R.ZO;
@@ -213,7 +227,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       const float a0 = fminf(0.99f, oG.x), a1 = fminf(0.99f, oG.y);
       return f32x2{((power.x > 0.0f) || (a0 < 1.0f / 255.0f)) ? 0.f : a0, ((power.y > 0.0f) || (a1 < 1.0f / 255.0f)) ? 0.f : a1};
     };
-    auto alpha2_of = [&](int j) -> f32x2 { return alpha2_rec(rec3_of(j)); };
+    auto alpha2_of = [&](uint32_t buf, int j) -> f32x2 { return alpha2_rec(rec3_of(buf, j)); };
     float al[NSTEP];          // the alphas of my FIRST chunk stay in registers: its blend evaluates no exp.  (The second
                               // chunk of a round -- blocks with more than NW/2 live chunks -- is staged last, so its records
                               // are still in recP when it is blended: its alphas are evaluated again there.)
@@ -229,16 +243,14 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
       }
       float tp = 1.0f;
       if (hasq) {
-        // lane e stages entry e of the chunk
-        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+        // lane e stages entry e of the chunk: its record (round 0: already in place, see the fill), its colour row
         float4 rq = make_float4(0, 0, 0, __uint_as_float(0u));
         float fv[NVF > 0 ? NVF : 1];
 #pragma unroll
         for (int i = 0; i < (NVF > 0 ? NVF : 1); i++) fv[i] = 0.f;
         const bool valid = (uint32_t)lane < nmy[q];
-        if (valid) {
-          const uint32_t id = my_surv[qhead + ci * CHS + (uint32_t)lane];
-          g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
+        float* rp = reinterpret_cast<float*>(&recP[ci][0]) + (((lane >> 2) * 2 + (lane & 1)) * 12 + ((lane >> 1) & 1));
+        auto colour_row = [&](uint32_t id) {
           const uint32_t gid = gauss_of(r, id);
           const uint32_t cid = r.colors_per_view ? id : gid;  // colour row: per view when it comes from SH
           rq = make_float4(r.colors[(size_t)cid * 3], r.colors[(size_t)cid * 3 + 1], r.colors[(size_t)cid * 3 + 2],
@@ -249,33 +261,45 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
               for (int i = 0; i < NVF; i++) fv[i] = r.feats[(size_t)gid * F + i];
             }
           }
-        }
-        wave_lds_sync();  // this wave's readers of recP (the previous chunk's phase A) are done
-        {
-          float* rp = reinterpret_cast<float*>(&recP[w][0]) + (((lane >> 2) * 2 + (lane & 1)) * 12 + ((lane >> 1) & 1));
+        };
+        if (round == 0) {  // (workgroup-uniform)
+          if (valid) colour_row(sid[ci * CHS + (uint32_t)lane]);
+          // entries past the chunk's end: opacity 0 => alpha 0 => skipped (no bounds test per step), finite everywhere.  (Both
+          // waves of the pair write these same zeros, each before its own reads.)
+          else { rp[0] = 0.f; rp[2] = 0.f; rp[4] = 0.f; rp[6] = 0.f; rp[8] = 0.f; rp[10] = 0.f; }
+        } else {
+          float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
+          if (valid) {
+            const uint32_t id = my_surv[qhead + ci * CHS + (uint32_t)lane];
+            g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
+            colour_row(id);
+          }
+          // (both waves of the pair write the same values to the chunk's buffer, each before its own reads; the other readers of
+          //  this buffer -- the previous round's phase B -- are behind the list barrier)
           rp[0] = g0.x; rp[2] = g0.y; rp[4] = g0.z; rp[6] = g0.w; rp[8] = g1.x;
-          rp[10] = valid ? g1.y : 0.f;  // opacity 0 => alpha 0 => skipped: no bounds test per step
-        }
-        rowq[w][q][lane] = rq;
-        if constexpr (NVF > 0) {
-#pragma unroll
-          for (int i = 0; i < NVF; i++) rowf[(((size_t)w * NS + q) * CHS + lane) * NVF + i] = fv[i];
+          rp[10] = valid ? g1.y : 0.f;
         }
         wave_lds_sync();
         if (q == 0) MGS_TRACE(3 + 8 * round);
         // straight-line: no per-step branch (an entry past the chunk's end has opacity 0 => alpha 0), so that the
         // compiler batches the LDS reads of several steps ahead of their use
         f32x2 tp2 = {1.0f, 1.0f};
-        Rec3 Rn = rec3_of(0);  // the records of a double step are read one double step ahead of their use
+        Rec3 Rn = rec3_of(ci, 0);  // the records of a double step are read one double step ahead of their use
 #pragma unroll
         for (int j = 0; j < NSTEP / 2; j++) {
           const Rec3 Rc = Rn;
-          if (j + 1 < NSTEP / 2) Rn = rec3_of(j + 1);
+          if (j + 1 < NSTEP / 2) Rn = rec3_of(ci, j + 1);
           const f32x2 a2 = alpha2_rec(Rc);
           if (q == 0) { al[2 * j] = a2.x; al[2 * j + 1] = a2.y; }
           tp2 = tp2 * (1.0f - a2);
         }
         tp = tp2.x * tp2.y;
+        // the colour rows are needed by the blend only: written now, their round trip lay behind the alphas
+        rowq[w][q][lane] = rq;
+        if constexpr (NVF > 0) {
+#pragma unroll
+          for (int i = 0; i < NVF; i++) rowf[(((size_t)w * NS + q) * CHS + lane) * NVF + i] = fv[i];
+        }
         float t0 = tp, t1 = tp;
         swap32(t0, t1);       // t0: the even entries' product, t1: the odd entries', in both lanes of the pixel
         tp = t0 * t1;
@@ -358,7 +382,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
             for (int u4 = 0; u4 < GS; u4++) {
               const int s = g * GS + u4;
-              if (q != 0 && (u4 & 1) == 0) a2q = alpha2_of(s >> 1);
+              if (q != 0 && (u4 & 1) == 0) a2q = alpha2_of(ci, s >> 1);
               float a0 = (q == 0) ? al[s] : ((u4 & 1) ? a2q.y : a2q.x), a1 = a0;
               swap32(a0, a1);  // a0 = alpha of entry 2s, a1 = alpha of entry 2s + 1 for my pixel, in both of its lanes
               // two entries of the reference's per-pixel walk (forward.cu:357-380).  A live pixel always has T >= 1e-4 (it

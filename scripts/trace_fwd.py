@@ -52,3 +52,10 @@ print("block duration: min", ends.min(), "mean", int(ends.mean()), "p90", int(np
 worst = int(np.argmax(ends))
 print("slowest block", worst, {e: int(rel[worst, :, e].max()) for e in names})
 print("blocks with a second round:", int((rel[:, :, 9] >= 0).any(1).sum()))
+# per WAVE (not per block): how long one wave spends between two of its own stamps
+for a, b, n in ((2, 3, "staging (list barrier -> rows staged)"), (3, 4, "phase A (rows staged -> phase A done)"),
+                (2, 4, "list barrier -> phase A done"), (5, 6, "phase B (Tp barrier -> phase B done)")):
+    m = (rel[:, :, a] >= 0) & (rel[:, :, b] >= 0)
+    d = (rel[:, :, b] - rel[:, :, a])[m]
+    if d.size:
+        print(f"  per wave {n:40s}: waves {d.size:5d} mean {d.mean():8.0f}  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}  max {d.max():8d}")
