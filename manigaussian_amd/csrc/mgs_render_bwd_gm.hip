@@ -506,29 +506,59 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
         for (int i = 0; i < 9; i++)
           if ((i & 1) == h) tr[n * TROW + NCT * 32 + i] = v[i];
         wave_lds_sync();
+        // (Every batch below first reads ALL its operands from LDS -- ids and sums, pinned by an opaque use -- and only then
+        //  issues its atomics.  Written as "read id, test, read sum, add" per instruction, the compiler emitted exactly that: two
+        //  dependent LDS round trips and a branch in front of each of the 22 atomic instructions, 5-7 k cycles per hand-over
+        //  and ~15 k of a block's 102 k at configs[2].)
         if constexpr (NCT > 0) {
           if (use_feat) {
 #pragma unroll
-            for (int k = 0; k < 16 * NCT; k++) {  // instruction k: Gaussians 2k', 2k'+1 of the tile half, 32 channels each
-              const int gg = 2 * (k % 16) + h, ch = 32 * (k / 16) + n;
-              const uint2 gi2 = gid[w][gg];
-              if (gi2.x != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)gi2.y * F + ch, tr[gg * TROW + ch]);
+            for (int ct = 0; ct < NCT; ct++) {  // instruction k of a tile: Gaussians 2k, 2k+1 of the group, 32 channels each
+              const int ch = 32 * ct + n;
+              uint2 g2[16];
+              float tv[16];
+#pragma unroll
+              for (int k = 0; k < 16; k++) {
+                const int gg = 2 * k + h;
+                g2[k] = gid[w][gg];
+                tv[k] = tr[gg * TROW + ch];
+              }
+#pragma unroll
+              for (int k = 0; k < 16; k++) asm volatile("" : "+v"(g2[k].x), "+v"(g2[k].y), "+v"(tv[k]));
+#pragma unroll
+              for (int k = 0; k < 16; k++)
+                if (g2[k].x != 0xffffffffu && ch < F) unsafeAtomicAdd(dL_dfeat + (size_t)g2[k].y * F + ch, tv[k]);
             }
           }
         }
+        {
+          uint32_t gq[4];
+          uint2 gc[2];
+          float tq[4], tc[2];
+          const int i8 = lane & 7, i4 = lane & 3;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {  // geometry sums: 8 Gaussians x 8 slots (6 used) per instruction
-          const int gg = 8 * k + (lane >> 3), i = lane & 7;
-          const uint32_t gi2 = gid[w][gg].x;
-          if (gi2 != 0xffffffffu && i < 6) unsafeAtomicAdd(acc8 + (size_t)gi2 * 8 + i, tr[gg * TROW + NCT * 32 + i]);
-        }
+          for (int k = 0; k < 4; k++) {  // geometry sums: 8 Gaussians x 8 slots (6 used) per instruction
+            const int gg = 8 * k + (lane >> 3);
+            gq[k] = gid[w][gg].x;
+            tq[k] = tr[gg * TROW + NCT * 32 + (i8 < 6 ? i8 : 0)];
+          }
 #pragma unroll
-        for (int k = 0; k < 2; k++) {  // colour sums: 16 Gaussians x 4 slots (3 used) per instruction
-          const int gg = 16 * k + (lane >> 2), i = lane & 3;
-          const uint2 gi2 = gid[w][gg];
-          if (gi2.x != 0xffffffffu && i < 3)
-            unsafeAtomicAdd(dL_dcolors + (size_t)(r.colors_per_view ? gi2.x : gi2.y) * 3 + i,
-                            tr[gg * TROW + NCT * 32 + 6 + i]);
+          for (int k = 0; k < 2; k++) {  // colour sums: 16 Gaussians x 4 slots (3 used) per instruction
+            const int gg = 16 * k + (lane >> 2);
+            gc[k] = gid[w][gg];
+            tc[k] = tr[gg * TROW + NCT * 32 + 6 + (i4 < 3 ? i4 : 0)];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) asm volatile("" : "+v"(gq[k]), "+v"(tq[k]));
+#pragma unroll
+          for (int k = 0; k < 2; k++) asm volatile("" : "+v"(gc[k].x), "+v"(gc[k].y), "+v"(tc[k]));
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (gq[k] != 0xffffffffu && i8 < 6) unsafeAtomicAdd(acc8 + (size_t)gq[k] * 8 + i8, tq[k]);
+#pragma unroll
+          for (int k = 0; k < 2; k++)
+            if (gc[k].x != 0xffffffffu && i4 < 3)
+              unsafeAtomicAdd(dL_dcolors + (size_t)(r.colors_per_view ? gc[k].x : gc[k].y) * 3 + i4, tc[k]);
         }
         wave_lds_sync();  // tr / gid are rewritten by the next group
         if (first_it) MGS_BTRACE(g == 0 ? 9 : 7);
