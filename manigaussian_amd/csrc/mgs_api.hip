@@ -143,6 +143,12 @@ static int check_common(const MgsRasterArgs* a) {
         set_error("feature width F=%d not compiled in (supported: 3,4,8,16,32,64; pad to the next one)", a->F);
         return MGS_ERR_INVALID_ARG;
       }
+      // the render forward addresses feature rows by 32-bit byte offsets (buffer loads)
+      if ((unsigned long long)a->P * (unsigned long long)a->F * 4ull >= (1ull << 32)) {
+        set_error("P * F * 4 = %llu bytes of features: rows are addressed by 32-bit offsets (< 4 GiB)",
+                  (unsigned long long)a->P * (unsigned long long)a->F * 4ull);
+        return MGS_ERR_INVALID_ARG;
+      }
     }
   }
   return MGS_OK;

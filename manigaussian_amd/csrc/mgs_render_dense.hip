@@ -104,6 +104,9 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   const bool insidex = pix_blk(r, tile, sub, pixx).inside; // k = 0 lanes their own, k = 1 lanes the other half's (64 in all)
   const uint2 rng = ranges[tile];
   const bool use_feat = (F > 0) && r.include_feature;
+  // the feature table as a buffer resource (wave-uniform: kernel argument); rows are addressed by 32-bit byte offsets, which
+  // the host side guarantees to fit (mgs_api.hip: P F 4 < 2^32)
+  const auto feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.feats), 0, 0xffffffffu, 0x00020000);
   uint32_t* __restrict__ my_rounds = round_base + round_entry(rng.x, tile, sub, 0);  // entry of round k: my_rounds[4 * k]
   bool overflow = false;   // the chunk pool ran out (workgroup-uniform): stop, the host will see the flag
   uint32_t* my_surv = surv + (size_t)sub * surv_stride + rng.x;  // this block's compacted list of instance ids: at most len entries
@@ -263,16 +266,23 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
           }
         };
         if (round == 0) {  // (workgroup-uniform)
-          if (valid) colour_row(sid[ci * CHS + (uint32_t)lane]);
-          // entries past the chunk's end: opacity 0 => alpha 0 => skipped (no bounds test per step), finite everywhere.  (Both
-          // waves of the pair write these same zeros, each before its own reads.)
-          else { rp[0] = 0.f; rp[2] = 0.f; rp[4] = 0.f; rp[6] = 0.f; rp[8] = 0.f; rp[10] = 0.f; }
+          if (valid) {
+            colour_row(sid[ci * CHS + (uint32_t)lane]);
+          } else {
+            // entries past the chunk's end: opacity 0 => alpha 0 => skipped (no bounds test per step), finite everywhere (both
+            // waves of the pair write these same zeros, each before its own reads); their feature row is the chunk's first
+            // Gaussian's -- a row the blend reads anyway, here with weight 0
+            rp[0] = 0.f; rp[2] = 0.f; rp[4] = 0.f; rp[6] = 0.f; rp[8] = 0.f; rp[10] = 0.f;
+            rq.w = __uint_as_float(gauss_of(r, sid[ci * CHS]));
+          }
         } else {
           float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, -1.f, -1.f);
           if (valid) {
             const uint32_t id = my_surv[qhead + ci * CHS + (uint32_t)lane];
             g0 = r.rec[2 * (size_t)id]; g1 = r.rec[2 * (size_t)id + 1];
             colour_row(id);
+          } else {
+            rq.w = __uint_as_float(gauss_of(r, my_surv[qhead + ci * CHS]));
           }
           // (both waves of the pair write the same values to the chunk's buffer, each before its own reads; the other readers of
           //  this buffer -- the previous round's phase B -- are behind the list barrier)
@@ -354,13 +364,17 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
         // the wait for a load happens BD steps after its issue, not at it); the row's Gaussian comes from LDS one step
         // before its load is issued.
         uint32_t gnext = __float_as_uint(rowq[w][q][k].w);  // Gaussian of entry 2s + k for the next load_B(s)
+        // (buffer loads: one 32-bit offset per row -- the flat form spent four VALU instructions per step on a 64-bit address;
+        //  an entry past the chunk's end names the chunk's FIRST Gaussian, see the staging: a row that is read anyway, weight 0)
         auto load_B = [&](int s) {
-          const uint32_t gide = gnext;                        // (0 for an entry past the chunk's end: a valid row)
+          const uint32_t gide = gnext;
           if (s + 1 < NSTEP) gnext = __float_as_uint(rowq[w][q][2 * (s + 1) + k].w);
 #pragma unroll
           for (int t = 0; t < (NT > 0 ? NT : 1); t++) {
             const int ch = 32 * t + pl;
-            if constexpr (MF) Bq[t][s % BD] = r.feats[(size_t)gide * F + (ch < F ? ch : 0)];
+            if constexpr (MF)
+              Bq[t][s % BD] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  feat_rsrc, gide * (uint32_t)(F * 4) + (uint32_t)((ch < F ? ch : 0) * 4), 0, 0));
           }
         };
         if constexpr (MF) {
@@ -410,8 +424,11 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
               if constexpr (MF) {
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                  const bool okb = (uint32_t)(2 * s + k) < n_my && (32 * t + pl) < F && use_feat;
-                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk, okb ? Bq[t][s % BD] : 0.f, acc[t], 0, 0, 0);
+                  // (an entry past the chunk's end has weight 0 and a real row: no select.  F is the template's width, i.e.
+                  //  features ARE rendered; only a last, partial tile of channels needs its padding lanes zeroed.)
+                  float bv = Bq[t][s % BD];
+                  if constexpr (F % 32 != 0) bv = (32 * t + pl) < F ? bv : 0.f;
+                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk, bv, acc[t], 0, 0, 0);
                 }
                 if (s + BD < NSTEP) load_B(s + BD);  // refill the ring slot just used
               }
