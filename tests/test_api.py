@@ -185,3 +185,26 @@ def test_forward_mode_and_overflow_policy_switches_validate_their_argument():
             mg.set_overflow_policy("ignore")
     finally:
         mg.set_overflow_policy(oldp)
+
+
+def test_feature_tables_beyond_32_bit_offsets_are_refused_before_any_launch():
+    """The render forward addresses feature rows by 32-bit byte offsets (buffer loads): P * F * 4 >= 4 GiB is an argument error,
+    reported by the argument check that runs before the first HIP call (so this runs without a GPU; the pointers below are
+    never dereferenced)."""
+    import ctypes
+    a = _lib.MgsRasterArgs()
+    a.P, a.D, a.M, a.F, a.W, a.H = 40_000_000, 1, 4, 32, 128, 128
+    a.tanfovx = a.tanfovy = 0.5
+    a.scale_modifier = 1.0
+    a.include_feature = 1
+    fake = ctypes.c_void_p(0x10000)
+    for n in ("background", "means3D", "shs", "language_feature", "opacities", "scales", "rotations", "viewmatrix",
+              "projmatrix", "campos"):
+        setattr(a, n, fake)
+    nr = ctypes.c_int32(-7)
+    L = _lib.lib()
+    L.mgs_rasterize_forward_preprocess.restype = ctypes.c_int
+    rc = L.mgs_rasterize_forward_preprocess(ctypes.byref(a), None, ctypes.byref(nr), None)
+    assert rc == -1, rc  # MGS_ERR_INVALID_ARG
+    assert "32-bit offsets" in _lib.last_error()
+    a.P = 1000  # the same arguments at a legal size pass the argument check (and would go on to the device): not called here
