@@ -197,9 +197,7 @@ int mgs_forward_result(const MgsRasterArgs* a, const uint64_t* host_status, int3
  *   dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscales [P,3], dL_drotations [P,4],
  *   dL_dconic [P,4] (optional, may be NULL; reference keeps it internal).
  * scratch: >= mgs_backward_scratch_bytes(P, M, F) device bytes, contents undefined on entry.
- * a->language_feature must be 16-byte aligned (feature rows are read as float4; MGS_ERR_INVALID_ARG otherwise), and the table
- * smaller than 4 GiB (P * F * 4 < 2^32: the render forward addresses its rows by 32-bit byte offsets; checked by every entry
- * point before its first launch). */
+ * a->language_feature must be 16-byte aligned (feature rows are read as float4; MGS_ERR_INVALID_ARG otherwise). */
 /* num_rendered: the forward's count, or -1 if the caller has not looked yet (asynchronous forward). */
 int mgs_rasterize_backward(const MgsRasterArgs* a, int32_t num_rendered, const int32_t* radii,
                            const float* dL_dout_color, const float* dL_dout_feature, float* dL_dmeans2D,
