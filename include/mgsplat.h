@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 7
+#define MGS_ABI_VERSION 8
 
 /* error codes */
 #define MGS_OK 0
@@ -44,6 +44,10 @@ extern "C" {
 #define MGS_ERR_NON_RGB (-4)       /* reference: "For non-RGB, provide precomputed Gaussian colors!" */
 #define MGS_NEED_CAPACITY 1        /* the binning workspace holds fewer instances / chunk records than this scene needs */
 #define MGS_PENDING 2              /* mgs_forward_result: the device has not reported yet */
+#define MGS_RETRY_TABLE_INIT 3     /* mgs_forward_result (ABI v8): the preprocess launch's table hand-shake gave up (a workgroup
+                                      made no progress for ~1 s): nothing was binned, the images are background only.  Run the
+                                      forward again on the same workspaces with opt.table_init = 1 (a blocking forward does that
+                                      by itself; an asynchronous one reports it here instead of a generic MGS_ERR_HIP) */
 
 #define MGS_MAX_FEATURE_CHANNELS 64
 
@@ -57,13 +61,16 @@ typedef struct MgsOptions {
   int32_t tight_bins;   /* 1*: drop (Gaussian, tile) instances whose alpha >= 1/255 footprint misses the tile      */
   int32_t fast_exp;     /* 0*: the reference's exp, bit for bit (ocml expf); 1: v_exp_f32 (rel. error ~2e-7 |x|, -2.4 % time) */
   int32_t exact_cull;   /* 1*: exact ellipse-vs-block test on top of the bounding-box test in the render forward   */
-  int32_t bin_mode;     /* 1*: the bin scatter keeps its per-tile tables in LDS (up to 4096 tiles; more: as 0);
-                           0: tables in memory, one atomic per instance -- any tile count.  Same sort + merge after either */
+  int32_t bin_mode;     /* 2*: per-tile tables in LDS (up to 4096 tiles; more: as 0) and the lists ordered by ONE bucket-rank
+                           launch (one workgroup per tile, keys in registers / LDS: ABI v8); 1: tables in LDS, segment sort +
+                           rank merge (rounds 2-5); 0: tables in memory, one atomic per instance, segment sort + rank merge --
+                           any tile count.  Every mode yields the reference's per-tile order (depth bits, then index)     */
   int32_t seg;          /* 2048*: keys per LDS-sorted segment (512, 1024, 2048, 4096: for lists of >> 8192 per tile)  */
   int32_t gm_waves;     /* 12*: render backward (one workgroup per CU): 12 waves x 168 registers, two pixels per step;
                            16 / 8: the one-pixel-per-step forms of rounds 2-4 (16 x 128 / 8 x 256 registers)            */
   int32_t dbg;          /* 0*: diagnostics (256: phase timeline of the render forward, mgs_debug_read_trace; 512: test
-                           hook -- the table-zeroing workgroup of the forward preprocess sleeps ~0.3 ms first)          */
+                           hook -- the table-zeroing workgroup of the forward preprocess sleeps ~0.3 ms first; 1024: test
+                           hook -- it never publishes the tables, the hand-shake gives up after ~1 s)                     */
   int32_t table_init;   /* 0*: the forward preprocess launch zeroes its own tile tables (workgroup 0 + a bounded hand-shake:
                            one launch fewer); 1: a zero-fill launch ahead of it -- no workgroup ever waits for another.
                            debug = 1 implies 1; a blocking forward whose hand-shake gave up re-runs itself with 1           */
@@ -182,7 +189,8 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
 /* Host-side decode of the status words of a forward (no HIP call, never blocks).  `a`: the arguments of that forward
  * (status_tag, binning_capacity, chunk_pool, binning_bytes and the shape are read).  Returns MGS_PENDING until both words
  * carry this call's tag; then MGS_OK, MGS_NEED_CAPACITY (instances > capacity, or the chunk pool overflowed: the images
- * and any backward of that forward are invalid) or MGS_ERR_INVALID_ARG (prefiltered violation).  *num_rendered and
+ * and any backward of that forward are invalid), MGS_RETRY_TABLE_INIT (see the code) or MGS_ERR_INVALID_ARG (prefiltered
+ * violation).  *num_rendered and
  * *chunks_used (each optional) receive the counts as soon as their word has arrived (-1 before); *ref_rendered (optional)
  * the reference's num_rendered (the 3-sigma-rect instances, RAST/cuda_rasterizer/rasterizer_impl.cu:280-284): the same
  * integer the blocking entry points return, so every path hands the caller one number. */
@@ -327,6 +335,15 @@ int mgs_forward_stats(const MgsRasterArgs* a, int32_t V, int64_t* incidences, in
  * cov3D f32[6P] (the reference's GeometryState: RAST/cuda_rasterizer/rasterizer_impl.h:30-46).  The parity tests compare
  * them bit for bit with the reference kernels' values. */
 int mgs_debug_geom_layout(int P, int M, int W, int H, size_t* depths, size_t* rec, size_t* rgb, size_t* cov3D);
+
+/* Diagnostic: where the binning of a forward left its per-tile lists.  `a` = that forward's arguments (its binning_bytes /
+ * binning_capacity / chunk_pool describe the carving), V = 0 for a single view or the number of views of a batch.  Byte offsets
+ * inside the binning workspace of keys_unsorted u64[capacity] (depth bits << 32 | id, tile-major, unordered inside a tile) and
+ * point_list u32[capacity] (sorted ids), and inside the img workspace of ranges uint2[tiles] ({first, end} of each tile's slice).
+ * The parity tests check that every tile's list is its slice of keys in (depth bits, id) order -- the reference's order
+ * (RAST/cuda_rasterizer/rasterizer_impl.cu:306-320). */
+int mgs_debug_binning_layout(const MgsRasterArgs* a, int32_t V, size_t* keys_unsorted, size_t* point_list, size_t* img_ranges,
+                             int32_t* capacity);
 
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */

@@ -229,10 +229,13 @@ def recover_forward(handle, radii, dev):
     p, a = handle.pending, handle.a
     V = handle.views[1] if handle.views is not None else 0
     W, H, F = int(a.W), int(a.H), int(a.F) if a.include_feature else 0
-    R = max(int(p.num_rendered), 0)
-    cap = R + R // 4 + 4096
-    nbytes = L.mgs_views_binning_bytes2(cap, 0, W, H, F, V) if V else L.mgs_binning_bytes2(cap, 0, W, H, F)
-    binning = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    handshake_only = p.rc == _lib.MGS_RETRY_TABLE_INIT
+    binning = None
+    if not handshake_only:
+        R = max(int(p.num_rendered), 0)
+        cap = R + R // 4 + 4096
+        nbytes = L.mgs_views_binning_bytes2(cap, 0, W, H, F, V) if V else L.mgs_binning_bytes2(cap, 0, W, H, F)
+        binning = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     out_color = handle.outs[0]() if handle.outs and handle.outs[0] is not None else None
     out_feat = handle.outs[1]() if handle.outs and handle.outs[1] is not None else None
     lead = (V,) if V else ()
@@ -240,7 +243,12 @@ def recover_forward(handle, radii, dev):
         out_color = torch.empty(lead + (3, H, W), dtype=_F32, device=dev)
     if a.include_feature and out_feat is None:
         out_feat = torch.empty(lead + (F, H, W), dtype=_F32, device=dev)
-    a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool, a.async_forward = binning.data_ptr(), nbytes, cap, 0, 0
+    if handshake_only:
+        # the scene did not outgrow anything: a workgroup of the preprocess launch gave up waiting for workgroup 0's zeroed
+        # tables.  Same workspace, tables zeroed by a launch of their own this time (no workgroup waits for another).
+        a.opt.set, a.opt.table_init, a.async_forward = 1, 1, 0
+    else:
+        a.binning, a.binning_bytes, a.binning_capacity, a.chunk_pool, a.async_forward = binning.data_ptr(), nbytes, cap, 0, 0
     a.bwd_accum, a.bwd_accum_bytes = None, 0  # the first run's preprocess zeroed the accumulators; nothing touched them since
     slot_ptr, tag = st.take_slot()
     a.status_tag = tag
@@ -250,7 +258,8 @@ def recover_forward(handle, radii, dev):
     st.add(newp)  # (the marks learn the binned count from its report)
     p.recovered = True
     handle.pending, handle.R = newp, R2
-    handle.keep = (handle.keep, binning)
+    if binning is not None:
+        handle.keep = (handle.keep, binning)
     return R2
 
 
@@ -375,6 +384,12 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         key = (P, W, H, F, opts["tight_bins"])
         T = ((W + 15) // 16) * ((H + 15) // 16)
         cannot_overflow, cap_worst, pool_worst = _worst_case(L, P, W, H, F, T, dev)
+        # ... charged against what live forwards of this device already hold (a node keeps its workspace until its backward):
+        # V forwards before the first backward take the worst case only while the SUM fits, the rest go by their marks
+        worst_bytes = _bin_bytes(L, cap_worst, pool_worst, W, H, F) if cannot_overflow else 0
+        if cannot_overflow and not blocking and _state.forward_mode() != "async" and \
+                not _state.worst_case_fits(st.index, worst_bytes, dev):
+            cannot_overflow = False
         guess = (cap_worst, pool_worst) if cannot_overflow else st.guess(key)  # worst case: no marks, no warm-up call needed
         # prefiltered=True is a checked promise (the reference traps the device): its violation must surface in this call
         lazy = (guess is not None and not blocking and not debug and not prefiltered and
@@ -397,7 +412,19 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
             p_geom, p_img, p_bin = ws3[0].data_ptr(), ws3[1].data_ptr(), ws3[2].data_ptr()
             ws = None
         else:
-            ws = torch.empty((gb + ib + bb,), **u8)
+            try:
+                ws = torch.empty((gb + ib + bb,), **u8)
+            except torch.cuda.OutOfMemoryError:
+                if not (lazy and cannot_overflow) or capturing:
+                    raise
+                # the allocator cannot give the worst case: this forward goes by its marks and waits for the preprocess
+                lazy, cannot_overflow = False, False
+                m = st.marks.get(key)
+                cap, pool = (m[0] + m[0] // 4 + 4096 if m else 4 * P + 4096), 0
+                bb = _bin_bytes(L, cap, pool, W, H, F)
+                ws = torch.empty((gb + ib + bb,), **u8)
+            if lazy and cannot_overflow and want_grad_buffer:
+                _state.hold(st.index, worst_bytes, ws)
             p_geom = ws.data_ptr()
             p_img, p_bin = p_geom + gb, p_geom + gb + ib
         if include_feature:
@@ -476,10 +503,14 @@ def _settle(handle, radii, dev, count):
     p = handle.pending
     if p is None:
         return count
-    if p.rc == _lib.MGS_NEED_CAPACITY and not p.captured:
+    if p.rc in (_lib.MGS_NEED_CAPACITY, _lib.MGS_RETRY_TABLE_INIT) and not p.captured:
         if _state.overflow_policy() == "raise":
             _state.device_state(dev).drain()  # folds the report into the marks and raises ...
             # ... unless an earlier drain already did:
+            if p.rc == _lib.MGS_RETRY_TABLE_INIT:
+                raise RuntimeError("the preprocess of this backward's asynchronous forward gave up waiting for its zeroed tile "
+                                   "tables and binned nothing: its images are incomplete and the step is lost (overflow policy "
+                                   "'raise')")
             raise RuntimeError("the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past "
                                "the head-room over earlier calls of its shape): its images are incomplete and the step is "
                                "lost; the next call of the shape gets a larger workspace (overflow policy 'raise')")

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgsplat.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_i32 = ctypes.c_int32
@@ -19,6 +19,7 @@ c_sz = ctypes.c_size_t
 MGS_OK, MGS_ERR_INVALID_ARG, MGS_ERR_HIP, MGS_ERR_WORKSPACE, MGS_ERR_NON_RGB = 0, -1, -2, -3, -4
 MGS_NEED_CAPACITY = 1
 MGS_PENDING = 2
+MGS_RETRY_TABLE_INIT = 3  # mgs_forward_result: the preprocess's table hand-shake gave up; re-run with table_init = 1
 
 SUPPORTED_F = (3, 4, 8, 16, 32, 64)
 
@@ -107,6 +108,8 @@ _EXPORTS = {
     "mgs_forward_stats": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(ctypes.c_int64),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), c_fp]),
     "mgs_debug_geom_layout": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.POINTER(c_sz)] * 4),
+    "mgs_debug_binning_layout": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32] + [ctypes.POINTER(c_sz)] * 3 +
+                                 [ctypes.POINTER(c_i32)]),
     "mgs_debug_read_trace": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bwd": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_selftest": (ctypes.c_int, [c_fp]),
@@ -157,7 +160,7 @@ def check(rc: int, what: str):
 
 # Per-call tuning switches (MgsOptions): the C ABI has no process-wide option state; this dict is merely the DEFAULT the
 # Python shim copies into every call's MgsRasterArgs.opt (a forward's values travel to its backward in the autograd ctx).
-DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=1, seg=2048, gm_waves=12, dbg=0, table_init=0)
+DEFAULT_OPTIONS = dict(tight_bins=1, fast_exp=0, exact_cull=1, bin_mode=2, seg=2048, gm_waves=12, dbg=0, table_init=0)
 OPTIONS_VERSION = [0]  # bumped by set_option: callers that cache a filled MgsOptions key it on this
 
 

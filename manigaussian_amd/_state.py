@@ -33,6 +33,7 @@ import ctypes
 import os
 import threading
 import warnings
+import weakref
 
 import torch
 
@@ -182,6 +183,38 @@ def safe_bytes(dev=None) -> int:
     return v
 
 
+# ---- worst-case workspaces that live forwards still hold: the budget is charged against their SUM per device -----------------
+# (round 5 tested it per call: V forwards before the first backward pinned V x 4 GB at BASELINE configs[2].)  The compiled
+# binding keeps the counter when it is loaded (its own forwards charge it too); else this dict does.
+_HELD = {}
+
+
+def held_bytes(index: int) -> int:
+    """Bytes of worst-case workspaces live forwards hold on device `index`."""
+    e = _EXT[0]
+    return int(e.held_bytes(index)) if e else _HELD.get(index, 0)
+
+
+def _hold_add(index, delta):
+    e = _EXT[0]
+    if e:
+        e.hold_add(index, int(delta))
+    else:
+        with _LOCK:
+            _HELD[index] = _HELD.get(index, 0) + int(delta)
+
+
+def hold(index: int, nbytes: int, owner):
+    """Charge `nbytes` against device `index`'s budget until `owner` (the workspace tensor) is freed."""
+    _hold_add(index, nbytes)
+    weakref.finalize(owner, _hold_add, index, -int(nbytes))
+
+
+def worst_case_fits(index: int, nbytes: int, dev=None) -> bool:
+    """May a forward take a worst-case workspace of `nbytes` now?  (what is held + this one) <= the budget."""
+    return held_bytes(index) + int(nbytes) <= safe_bytes(dev)
+
+
 def set_headroom(instances: float = None, chunks: float = None):
     """Factors (>= 1) by which an asynchronous forward's instance list / chunk-record pool exceed the largest count seen."""
     for k, v in (("instances", instances), ("chunks", chunks)):
@@ -268,6 +301,7 @@ class _Marks(collections.abc.MutableMapping):
 class DeviceState:
     def __init__(self, dev):
         self.dev = dev
+        self.index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.status = torch.full((SLOT_WORDS * NSLOTS,), -1, dtype=torch.int64).pin_memory()
         self.base_ptr = self.status.data_ptr()
         words = self.status.numpy()
@@ -277,7 +311,7 @@ class DeviceState:
         self.next_slot = 0
         # shape key -> [instances high-water, chunk records high-water or None (unknown: worst case)]
         e = ext()
-        self.marks = _Marks(e, dev.index if dev.index is not None else torch.cuda.current_device()) if e else {}
+        self.marks = _Marks(e, self.index) if e else {}
         self.pending = collections.deque()
         self.captured = []   # forwards recorded into HIP graphs: their slots stay reserved, check_status() reads them
         self.deferred = collections.deque(maxlen=64)  # overflowed forwards whose backward will re-render (diagnostics)
@@ -308,7 +342,7 @@ class DeviceState:
                 self.pending.append(pending)
                 e = _EXT[0]
                 if e:  # the binding's hot path looks at this side's reports too while some are outstanding
-                    e.set_python_pending(len(self.pending))
+                    e.set_python_pending(self.index, len(self.pending))
 
     # ---- high-water marks ---------------------------------------------------------------------------------------
     def guess(self, key):
@@ -334,7 +368,7 @@ class DeviceState:
         outstanding).  Raises if a forward overflowed its workspace or finished without reporting."""
         e = _EXT[0]
         if e and not _from_ext:  # reports of forwards the compiled binding enqueued on this device
-            e.check_status(self.dev.index if self.dev.index is not None else torch.cuda.current_device(), wait)
+            e.check_status(self.index, wait)
         if not self.pending:
             return
         failed = None
@@ -359,7 +393,7 @@ class DeviceState:
                 failed = self._account(p, rc) or failed
             self.pending.extendleft(reversed(keep))  # ahead of anything appended meanwhile (nothing: we hold the lock)
             if e:
-                e.set_python_pending(len(self.pending))
+                e.set_python_pending(self.index, len(self.pending))
         if failed:
             raise RuntimeError(failed)
 
@@ -368,29 +402,35 @@ class DeviceState:
         if rc == _lib.MGS_OK:
             self.learn(p.key, p.num_rendered, p.chunks_used)
             return None
-        if rc == _lib.MGS_NEED_CAPACITY:
-            over_inst = p.num_rendered > p.cap > 0
-            self.learn(p.key, p.num_rendered if p.num_rendered >= 0 else None, None, pool_unknown=not over_inst)
-            what = (f"{p.num_rendered} (Gaussian, tile) instances > capacity {p.cap}" if over_inst else
-                    f"chunk pool of {p.pool} records")
-            msg = ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
-                   f"({what}): the images of THAT call were incomplete.  The marks are raised")
+        if rc in (_lib.MGS_NEED_CAPACITY, _lib.MGS_RETRY_TABLE_INIT):
+            grew = rc == _lib.MGS_NEED_CAPACITY
+            if grew:
+                over_inst = p.num_rendered > p.cap > 0
+                self.learn(p.key, p.num_rendered if p.num_rendered >= 0 else None, None, pool_unknown=not over_inst)
+                what = (f"{p.num_rendered} (Gaussian, tile) instances > capacity {p.cap}" if over_inst else
+                        f"chunk pool of {p.pool} records")
+                msg = ("an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape "
+                       f"({what}): the images of THAT call were incomplete.  The marks are raised")
+                hint = ("  For scenes that grow abruptly use manigaussian_amd.set_forward_mode('safe') (the default) or a larger "
+                        "set_headroom().")
+                hint2 = ", or use manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly."
+            else:  # nothing to learn: a workgroup of the preprocess launch was held back (include/mgsplat.h MGS_RETRY_TABLE_INIT)
+                msg = ("an asynchronous rasterizer forward's preprocess gave up waiting for its zeroed tile tables (a workgroup of "
+                       "the launch made no progress for about a second) and binned nothing: the images of THAT call were incomplete")
+                hint = "  manigaussian_amd.set_options(table_init=1) removes the hand-shake."
+                hint2 = " (manigaussian_amd.set_options(table_init=1) removes the hand-shake)."
             if p.recovered or (_OVERFLOW == "repair" and p.recoverable and not p.backward_enqueued and not p.captured):
                 # its backward re-renders first (manigaussian_amd._C.recover_forward): the gradients come from a complete
                 # forward; only what the caller computed from the incomplete images in between cannot be repaired
                 if not p.recovered:
                     self.deferred.append(p)
                 warnings.warn(msg + "; the call's backward re-renders on the blocking path before it runs, but a loss computed "
-                              "from those images was computed from incomplete images.  For scenes that grow abruptly use "
-                              "manigaussian_amd.set_forward_mode('safe') (the default) or a larger set_headroom().", RuntimeWarning,
-                              stacklevel=4)
+                              "from those images was computed from incomplete images." + hint, RuntimeWarning, stacklevel=4)
                 return None
             if p.recoverable and not p.backward_enqueued and not p.captured:  # (overflow policy "raise")
                 p.recovered = True  # its backward, if it still comes, raises too (manigaussian_amd._C._settle)
-                return (msg + "; the step is lost (overflow policy 'raise'): re-run it, or use "
-                        "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.")
-            return (msg + " and its gradients were computed on the incomplete state; re-run the step, or use "
-                    "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.")
+                return msg + "; the step is lost (overflow policy 'raise'): re-run it" + (hint2 if grew else ".")
+            return msg + " and its gradients were computed on the incomplete state; re-run the step" + hint2
         return f"rasterizer forward failed: {_lib.last_error()} (code {rc})"
 
     def check_captured(self):

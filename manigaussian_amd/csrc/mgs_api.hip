@@ -45,7 +45,7 @@ static Options options_of(const MgsRasterArgs* a) {
   Options o;
   if (a && a->opt.set) {
     o.tight_bins = a->opt.tight_bins; o.fast_exp = a->opt.fast_exp; o.exact_cull = a->opt.exact_cull;
-    o.bin_mode = a->opt.bin_mode ? 1 : 0; o.gm_waves = (a->opt.gm_waves == 8 || a->opt.gm_waves == 16) ? a->opt.gm_waves : 12; o.dbg = a->opt.dbg;
+    o.bin_mode = (a->opt.bin_mode >= 0 && a->opt.bin_mode <= 2) ? a->opt.bin_mode : 2; o.gm_waves = (a->opt.gm_waves == 8 || a->opt.gm_waves == 16) ? a->opt.gm_waves : 12; o.dbg = a->opt.dbg;
     o.seg = (a->opt.seg == 512 || a->opt.seg == 1024 || a->opt.seg == 4096) ? a->opt.seg : 2048;
     o.table_init = a->opt.table_init ? 1 : 0;
   }
@@ -187,7 +187,9 @@ int mgs_get_option(const char* key) {
 
 static int num_tiles(int W, int H) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 // the bin scatter keeps its per-tile tables in LDS; larger tile grids (or bin_mode 0) keep them in memory
-static bool lds_tables(const Options& o, int T) { return o.bin_mode == 1 && T <= LDS_TILES; }
+static bool lds_tables(const Options& o, int T) { return o.bin_mode >= 1 && T <= LDS_TILES; }
+// ... and the lists are ordered by ONE bucket-rank launch (bin_mode 2) instead of segment sort + rank merge
+static bool bucket_rank(const Options& o, int T) { return o.bin_mode == 2 && T <= LDS_TILES; }
 size_t mgs_geom_bytes(int P, int M, int W, int H) { size_t t; carve_geom(nullptr, P, M, num_tiles(W, H), 1, &t); return t; }
 size_t mgs_img_bytes(int W, int H) { size_t t; carve_img(nullptr, W, H, &t); return t; }
 static size_t binning_bytes_T(int R, int pool, int T, int F) {
@@ -266,7 +268,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   if (!handshake) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready;
   p.nonce = handshake ? next_nonce() : 0ull;
-  p.wg0_delay = (o.dbg & 512) ? 100 : 0;
+  p.wg0_delay = (o.dbg & 1024) ? -1 : (o.dbg & 512) ? 100 : 0;
   im.nonce = p.nonce;
   p.zero_ptr = nullptr; p.zero_f4 = 0;
   if (a->bwd_accum) {
@@ -356,7 +358,7 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
   const int F = a->include_feature ? a->F : 0;
   r.W = a->W; r.H = a->H; r.tiles_x = (a->W + TILE - 1) / TILE; r.tiles_y = (a->H + TILE - 1) / TILE;
   r.F = F; r.include_feature = F > 0;
-  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg & ~512;
+  r.fast_exp = o.fast_exp; r.exact_cull = o.exact_cull; r.gm_waves = o.gm_waves; r.dbg = o.dbg & ~(512 | 1024);
   r.nwf = fwd_waves(F, r.tiles_x * r.tiles_y);
   r.V = 1; r.Pg = a->P; r.Hv = a->H; r.Hp = a->H; r.colors_per_view = 0;
   r.bg = a->background;
@@ -388,8 +390,9 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   (void)radii;
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
-    MGS_STAGE(launch_bin_segsort(k, lds, g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream), "binning", a->debug,
-              stream);
+    if (k == 2 && bucket_rank(o, T)) break;  // (the bucket rank of stage 1 wrote the sorted ids)
+    MGS_STAGE(launch_bin_segsort(k, lds, bucket_rank(o, T), g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
+              "binning", a->debug, stream);
   }
   const RenderArgs r = render_args(a, o, g);
   { StageTimer t(ST_RENDER_FWD, stream);
@@ -515,7 +518,7 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
     // second): nothing was binned.  Run the forward again with the tables zeroed by a launch of their own -- no workgroup
     // waits for another on that path.  (The first run's kernels still report through the same words: drain them first.)
     MGS_HIP(hipStreamSynchronize(stream), "stream sync before the hand-shake retry");
-    o.table_init = 1; o.dbg &= ~512;
+    o.table_init = 1; o.dbg &= ~(512 | 1024);
     continue;
   }
   rc = check_prefiltered(fl);
@@ -541,7 +544,9 @@ static int forward_result_T(const MgsRasterArgs* a, int T, const uint64_t* host_
   }
   if (a1 && chunks_used) *chunks_used = (int32_t)(uint32_t)w1;
   if (a0) {
-    const int rc = check_prefiltered((uint32_t)(w0 >> 32) & 0xffffu);
+    const uint32_t fl = (uint32_t)(w0 >> 32) & 0xffffu;
+    if (fl & 2u) { set_error("%s", kHandshakeMsg); return MGS_RETRY_TABLE_INIT; }  // (nothing was binned; word 1 reports 0 chunks)
+    const int rc = check_prefiltered(fl);
     if (rc) return rc;
     if (a->P > 0) {
       const BinShape bs = bin_shape(a, T, a->include_feature ? a->F : 0);
@@ -764,7 +769,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   p.tile_hist = im.tile_hist; p.blk_base = lds ? g.blk_base : nullptr; p.ref_count = im.ref_count;
   p.tables = im.flags; p.tables_words = (uint32_t)(im.zero_bytes / 4); p.ready = im.ready;
   p.nonce = handshake ? next_nonce() : 0ull;
-  p.wg0_delay = (o.dbg & 512) ? 100 : 0;
+  p.wg0_delay = (o.dbg & 1024) ? -1 : (o.dbg & 512) ? 100 : 0;
   im.nonce = p.nonce;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_HIP(launch_preprocess_fwd(p, g, radii, stream), "preprocess (views)"); }
@@ -773,7 +778,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   const StatusSink status = {host_status, a->status_tag};
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
-    MGS_HIP(launch_bin_segsort(k, lds, g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
+    if (k == 2 && bucket_rank(o, at.T)) break;
+    MGS_HIP(launch_bin_segsort(k, lds, bucket_rank(o, at.T), g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
             "binning (views)");
   }
   const RenderArgs r = views_render_args(a, o, at, g);
@@ -914,6 +920,23 @@ int mgs_debug_geom_layout(int P, int M, int W, int H, size_t* depths, size_t* re
   if (rec) *rec = (size_t)(reinterpret_cast<char*>(g.rec) - base);
   if (rgb) *rgb = (size_t)(reinterpret_cast<char*>(g.rgb) - base);
   if (cov3D) *cov3D = (size_t)(reinterpret_cast<char*>(g.cov3D) - base);
+  return MGS_OK;
+}
+
+int mgs_debug_binning_layout(const MgsRasterArgs* a, int32_t V, size_t* keys_unsorted, size_t* point_list, size_t* img_ranges,
+                             int32_t* capacity) {
+  if (!a || a->W <= 0 || a->H <= 0) { set_error("binning_layout: bad argument"); return MGS_ERR_INVALID_ARG; }
+  const int F = a->include_feature ? a->F : 0;
+  const int T = V > 0 ? atlas_of(a->W, a->H, V).T : num_tiles(a->W, a->H);
+  const BinShape bs = bin_shape(a, T, F);
+  if (bs.cap < 0) { set_error("binning_layout: binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  char* const base = reinterpret_cast<char*>(ALIGN);
+  const BinView b = carve_binning(base, bs.cap, T, F, bs.pool, nullptr, nullptr);
+  const ImgView im = carve_img(base, a->W, V > 0 ? atlas_of(a->W, a->H, V).H : a->H, nullptr);
+  if (keys_unsorted) *keys_unsorted = (size_t)(reinterpret_cast<char*>(b.keys_unsorted) - base);
+  if (point_list) *point_list = (size_t)(reinterpret_cast<char*>(b.point_list) - base);
+  if (img_ranges) *img_ranges = (size_t)(reinterpret_cast<char*>(im.ranges) - base);
+  if (capacity) *capacity = bs.cap;
   return MGS_OK;
 }
 

@@ -546,6 +546,239 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32
   }
 }
 
+// ================================ bucket rank (round 6): ONE launch instead of segment sort + rank merge ==================
+// One workgroup of 1024 threads per tile; the tile's keys never leave the CU between "unsorted slice" and "sorted ids":
+//   1. the slice (<= BK_CAP keys) goes into REGISTERS (<= 16 keys per thread); min / max key of the tile (wave reduce + one
+//      LDS atomic per wave);
+//   2. an ORDER-PRESERVING bucket index per key: the top 24 significant bits of (key - min), scaled to NB buckets (a power of
+//      two between 256 and 4096, about two keys per bucket) -- a monotone function of the 64-bit key, so every key of
+//      bucket b precedes every key of bucket b + 1.  One returning LDS atomic per key counts the bucket and hands the key
+//      its arrival index;
+//   3. exclusive scan of the counts; the keys go to LDS grouped by bucket (start + arrival index);
+//   4. rank inside the bucket = how many of its keys are smaller (keys are unique: depth bits << 32 | id): final position
+//      = bucket start + rank -- the order of a stable sort by (depth bits, id), which is the reference's order
+//      (RAST/cuda_rasterizer/rasterizer_impl.cu:306-320: radix sort of tile << 32 | depth keys, stable in the id);
+//   5. the ids are put in order in LDS and leave with coalesced stores.
+// ~6 barriers and a handful of LDS operations per key against 66 dependent compare-exchange stages + a rank merge.
+// Depth distributions that defeat the buckets (sum of squared bucket counts > 64 per key: thousands of equal depths among
+// spread-out ones) take a bitonic network over the same LDS array instead -- bounded, never wrong.  Slices longer than BK_CAP
+// keys are cut by a coarse first-level histogram into consecutive key ranges of <= BK_CAP keys, each ranked as above (the
+// slice is streamed from L2 once per range); a coarse bucket that alone exceeds BK_CAP keys (more than 16 384 keys of one
+// tile within 1/256 of its depth range) is ranked against the streamed slice directly: slow, correct.
+constexpr int BK_THREADS = 1024;
+constexpr int BK_KPT = 16;                       // keys per thread
+constexpr int BK_CAP = BK_THREADS * BK_KPT;      // keys one pass holds
+constexpr int BK_NB_MAX = 4096;                  // fine buckets
+constexpr int BK_COARSE = 256;                   // first-level buckets of a slice longer than BK_CAP
+
+struct BkMap { uint64_t kmin; uint32_t shift; float scale; uint32_t nb; };
+__device__ __forceinline__ BkMap bk_map(uint64_t kmin, uint64_t kmax, uint32_t nb) {
+  BkMap m;
+  m.kmin = kmin; m.nb = nb;
+  const uint64_t r = kmax - kmin;
+  const int bits = r ? 64 - __builtin_clzll(r) : 0;
+  m.shift = bits > 24 ? (uint32_t)(bits - 24) : 0u;
+  m.scale = (float)nb / ((float)(uint32_t)(r >> m.shift) + 1.0f);
+  return m;
+}
+__device__ __forceinline__ uint32_t bk_bucket(const BkMap& m, uint64_t key) {
+  const uint32_t t = (uint32_t)((key - m.kmin) >> m.shift);   // < 2^24: exact as a float; monotone in key
+  const uint32_t b = (uint32_t)((float)t * m.scale);          // rounding and truncation keep the order
+  return b < m.nb ? b : m.nb - 1u;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v, int lane) {
+  uint64_t o;
+  o = lane_xor64<1>(v, lane); v = o < v ? o : v;
+  o = lane_xor64<2>(v, lane); v = o < v ? o : v;
+  o = lane_xor64<4>(v, lane); v = o < v ? o : v;
+  o = lane_xor64<8>(v, lane); v = o < v ? o : v;
+  o = lane_xor64<16>(v, lane); v = o < v ? o : v;
+  o = lane_xor64<32>(v, lane); v = o < v ? o : v;
+  return v;
+}
+
+struct BkShared {
+  uint64_t sk[BK_CAP];            // keys grouped by bucket; later the sorted ids (uint32) in its first half
+  uint32_t cnt[BK_NB_MAX + 1];    // bucket counts -> exclusive starts; cnt[nb] = n
+  uint32_t tmp[192];
+  unsigned long long kmin, kmax;
+  uint32_t total, sumsq, gath;
+};
+
+// Rank the n <= BK_CAP keys held in registers (key i of thread tid is element tid + 1024 i, i < kpt) and write their ids, in
+// order, to out[0 .. n).  All 1024 threads call it; n and kpt are workgroup-uniform.
+__device__ void bk_rank_emit(BkShared& S, uint64_t (&k)[BK_KPT], uint32_t n, int kpt, uint32_t* __restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  // ---- 1. min / max
+  uint64_t lo = ~0ull, hi = 0ull;
+#pragma unroll
+  for (int i = 0; i < BK_KPT; i++)
+    if (i < kpt && (uint32_t)tid + 1024u * i < n) { lo = k[i] < lo ? k[i] : lo; hi = k[i] > hi ? k[i] : hi; }
+  if (tid == 0) { S.kmin = ~0ull; S.kmax = 0ull; S.sumsq = 0u; }
+  uint32_t nb = 256;
+  while (nb < BK_NB_MAX && 2u * nb <= n) nb <<= 1;   // about two keys per bucket (n / 2 < nb <= n), 256 .. 4096
+  for (uint32_t b = tid; b <= nb; b += BK_THREADS) S.cnt[b] = 0u;
+  __syncthreads();
+  lo = wave_min_u64(lo, lane);
+  hi = ~wave_min_u64(~hi, lane);
+  if (lane == 0) { atomicMin(&S.kmin, (unsigned long long)lo); atomicMax(&S.kmax, (unsigned long long)hi); }
+  __syncthreads();
+  const BkMap m = bk_map(S.kmin, S.kmax, nb);
+  // ---- 2. bucket + arrival index (packed: bucket << 16 | arrival index, n <= 16 384)
+  uint32_t ba[BK_KPT];
+#pragma unroll
+  for (int i = 0; i < BK_KPT; i++) {
+    ba[i] = 0u;
+    if (i < kpt && (uint32_t)tid + 1024u * i < n) {
+      const uint32_t b = bk_bucket(m, k[i]);
+      ba[i] = (b << 16) | atomicAdd(&S.cnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  // ---- 3. skew measure, exclusive scan
+  {
+    uint32_t sq = 0u;
+    for (uint32_t b = tid; b < nb; b += BK_THREADS) { const uint32_t c = S.cnt[b]; sq += c * c; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sq += (uint32_t)__shfl_xor((int)sq, d, 64);
+    if (lane == 0 && sq) atomicAdd(&S.sumsq, sq);
+  }
+  block_exclusive_scan(S.cnt, (int)nb, S.tmp, &S.total);  // (its first barrier orders the reads above before its writes)
+  if (tid == 0) S.cnt[nb] = n;
+  const bool skewed = S.sumsq > 64u * n;  // (S.sumsq is complete: the scan's barriers came after every atomicAdd)
+  if (!skewed) {
+    // ---- 4. keys grouped by bucket; rank inside the bucket
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++)
+      if (i < kpt && (uint32_t)tid + 1024u * i < n) S.sk[S.cnt[ba[i] >> 16] + (ba[i] & 0xffffu)] = k[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++) {
+      if (i < kpt && (uint32_t)tid + 1024u * i < n) {
+        const uint32_t b = ba[i] >> 16;
+        const uint32_t b0 = S.cnt[b], b1 = S.cnt[b + 1u];
+        uint32_t r = 0u;
+        for (uint32_t j = b0; j < b1; j++) r += S.sk[j] < k[i] ? 1u : 0u;
+        ba[i] = b0 + r;  // the key's final position
+      }
+    }
+    __syncthreads();  // every read of sk is done: its first half becomes the id array
+    uint32_t* sid = reinterpret_cast<uint32_t*>(S.sk);
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++)
+      if (i < kpt && (uint32_t)tid + 1024u * i < n) sid[ba[i]] = (uint32_t)k[i];
+    __syncthreads();
+    for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = sid[j];
+  } else {
+    // ---- bitonic network over the LDS array (padded to a power of two with ~0)
+    uint32_t n2 = 128;
+    while (n2 < n) n2 <<= 1;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++) {
+      const uint32_t e = (uint32_t)tid + 1024u * i;
+      if (e < n2) S.sk[e] = (i < kpt && e < n) ? k[i] : ~0ull;
+    }
+    for (uint32_t kk = 2; kk <= n2; kk <<= 1)
+      for (uint32_t j = kk >> 1; j >= 1u; j >>= 1) {
+        __syncthreads();
+        for (uint32_t c = tid; c < (n2 >> 1); c += BK_THREADS) {
+          const uint32_t a = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), b = a | j;
+          const uint64_t x = S.sk[a], y = S.sk[b];
+          if ((x > y) == ((a & kk) == 0u)) { S.sk[a] = y; S.sk[b] = x; }
+        }
+      }
+    __syncthreads();
+    for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = (uint32_t)S.sk[j];
+  }
+  __syncthreads();  // LDS is reused by the next range of a long slice
+}
+
+__global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, const uint2* __restrict__ ranges,
+                                                                     const uint64_t* __restrict__ keys_unsorted,
+                                                                     uint32_t* __restrict__ point_list,
+                                                                     unsigned long long* hs_fail_mark) {
+  __shared__ BkShared S;
+  __shared__ uint32_t coarse[BK_COARSE + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile = (int)blockIdx.x;
+  // ImgView::ready[1], the preprocess's "a workgroup gave up waiting" mark: every workgroup of the bin scatter has read it
+  // (kernel boundary); cleared here so that a replayed HIP graph -- same buffer, same nonce -- does not see a stale failure
+  if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;
+  if (tile >= T) return;
+  const uint2 rng = ranges[tile];
+  const uint32_t L = rng.y - rng.x;
+  if (L == 0u) return;
+  const uint64_t* __restrict__ src = keys_unsorted + rng.x;
+  uint32_t* __restrict__ dst = point_list + rng.x;
+  uint64_t k[BK_KPT];
+  if (L <= (uint32_t)BK_CAP) {  // the whole slice in one pass
+    const int kpt = (int)((L + BK_THREADS - 1) / BK_THREADS);
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++) {
+      const uint32_t e = (uint32_t)tid + 1024u * i;
+      k[i] = (i < kpt && e < L) ? src[e] : ~0ull;
+    }
+    bk_rank_emit(S, k, L, kpt, dst);
+    return;
+  }
+  // ---- long slice: coarse histogram over the streamed slice -> consecutive key ranges of <= BK_CAP keys
+  uint64_t lo = ~0ull, hi = 0ull;
+  for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint64_t v = src[e]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  if (tid == 0) { S.kmin = ~0ull; S.kmax = 0ull; }
+  for (int b = tid; b <= BK_COARSE; b += BK_THREADS) coarse[b] = 0u;
+  __syncthreads();
+  lo = wave_min_u64(lo, lane);
+  hi = ~wave_min_u64(~hi, lane);
+  if (lane == 0) { atomicMin(&S.kmin, (unsigned long long)lo); atomicMax(&S.kmax, (unsigned long long)hi); }
+  __syncthreads();
+  const BkMap cm = bk_map(S.kmin, S.kmax, (uint32_t)BK_COARSE);
+  for (uint32_t e = tid; e < L; e += BK_THREADS) atomicAdd(&coarse[bk_bucket(cm, src[e])], 1u);
+  __syncthreads();
+  block_exclusive_scan(coarse, BK_COARSE, S.tmp, &S.total);
+  if (tid == 0) coarse[BK_COARSE] = L;
+  __syncthreads();
+  uint32_t b0 = 0u;
+  while (b0 < (uint32_t)BK_COARSE) {  // (workgroup-uniform: everybody reads the same table)
+    uint32_t b1 = b0 + 1u;
+    while (b1 < (uint32_t)BK_COARSE && coarse[b1 + 1u] - coarse[b0] <= (uint32_t)BK_CAP) b1++;
+    const uint32_t n = coarse[b1] - coarse[b0], first = coarse[b0];
+    if (n == 0u) { b0 = b1; continue; }
+    if (n <= (uint32_t)BK_CAP) {
+      // gather the range's keys into LDS (arrival order), then into registers
+      if (tid == 0) S.gath = 0u;
+      __syncthreads();
+      for (uint32_t e = tid; e < L; e += BK_THREADS) {
+        const uint64_t v = src[e];
+        const uint32_t b = bk_bucket(cm, v);
+        if (b >= b0 && b < b1) S.sk[atomicAdd(&S.gath, 1u)] = v;
+      }
+      __syncthreads();
+      const int kpt = (int)((n + BK_THREADS - 1) / BK_THREADS);
+#pragma unroll
+      for (int i = 0; i < BK_KPT; i++) {
+        const uint32_t e = (uint32_t)tid + 1024u * i;
+        k[i] = (i < kpt && e < n) ? S.sk[e] : ~0ull;
+      }
+      __syncthreads();
+      bk_rank_emit(S, k, n, kpt, dst + first);
+    } else {
+      // one coarse bucket holds more than BK_CAP keys: rank each of its keys against the streamed slice (slow, correct)
+      for (uint32_t e = tid; e < L; e += BK_THREADS) {
+        const uint64_t v = src[e];
+        if (bk_bucket(cm, v) != b0) continue;
+        uint32_t r = 0u;
+        for (uint32_t j = 0; j < L; j++) {
+          const uint64_t u = src[j];
+          r += (u < v && bk_bucket(cm, u) == b0) ? 1u : 0u;
+        }
+        dst[first + r] = (uint32_t)v;
+      }
+    }
+    b0 = b1;
+  }
+}
+
 template <int SEGN>
 static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im, int R, int T, hipStream_t s) {
   const int n_segments = R / SEGN + T;  // upper bound of sum_t ceil(L_t / SEGN); surplus workgroups exit at once
@@ -562,8 +795,8 @@ static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im,
                        b.seg_desc, b.keys, b.point_list);
 }
 
-hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V,
-                              int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
+hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const GeomView& g, const BinView& b, const ImgView& im, int Pg,
+                              int V, int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
@@ -583,6 +816,12 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, con
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
                        tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, im.ref_count, g.rect, g.depths,
                        im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready, im.nonce);
+    return hipGetLastError();
+  }
+  if (bucket) {  // which == 1: the bucket rank does the work of segment sort + rank merge; which == 2: nothing left to do
+    if (which == 1)
+      hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(T), dim3(BK_THREADS), 0, s, T, im.ranges, b.keys_unsorted, b.point_list,
+                         im.ready ? im.ready + 1 : nullptr);
     return hipGetLastError();
   }
   switch (seg) {

@@ -197,7 +197,9 @@ struct Options {
   int tight_bins = 1;      // 1: drop (Gaussian,tile) instances whose alpha>=1/255 footprint misses the tile
   int fast_exp = 0;        // 0: ocml's expf, bit for bit (exp_ocml_unclamped), 1: v_exp_f32 of x log2(e) (rel. error ~2e-7 |x|)
   int exact_cull = 1;      // exact ellipse-vs-block cull on top of the bbox cull in the render forward
-  int bin_mode = 1;        // 1: the bin scatter's tables in LDS (up to LDS_TILES tiles), 0: in memory (see mgs_binning.hip)
+  int bin_mode = 2;        // 2: tables in LDS + ONE bucket-rank launch; 1: tables in LDS (up to LDS_TILES tiles) + segment sort + rank
+                           // merge; 0: tables in memory + segment sort + rank merge (see mgs_binning.hip)
+  int rank_mode = 1;       // derived from bin_mode: 1 = bucket rank, 0 = segment sort + rank merge
   int seg = 2048;          // bin_mode 1: entries per LDS-sorted segment (512, 1024 or 2048)
   int gm_waves = 12;       // render backward at one workgroup per CU: 12 = 12 waves, two pixels per step; 16 / 8 = the one-pixel forms
   int dbg = 0;             // see RenderArgs::dbg
@@ -249,8 +251,9 @@ unsigned long long next_nonce();  // process-wide counter (never 0) mixed with a
 //  sort, 2 rank merge)
 // lds_tables: the scatter keeps the per-tile tables in LDS and uses the preprocess's reservations (T <= LDS_TILES); else a
 // one-workgroup table kernel + a scatter with one atomic per instance on cursors in memory (any tile count).
-hipError_t launch_bin_segsort(int which, bool lds_tables, const GeomView& g, const BinView& b, const ImgView& im, int Pg, int V,
-                              int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
+// bucket: stage 1 is the one-launch bucket rank (mgs_binning.hip, round 6) and stage 2 is empty, instead of segment sort + rank merge
+hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const GeomView& g, const BinView& b, const ImgView& im, int Pg,
+                              int V, int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj,
                                uint8_t* present, hipStream_t s);
 

@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   if constexpr (HIST) {
     if (blockIdx.x == 0) {
       if (a.nonce == 0ull) return;
+      if (a.wg0_delay < 0) return;  // (test hook, MgsOptions.dbg & 1024: the tables are never published -- the workers give up)
       for (int i = 0; i < a.wg0_delay; i++) __builtin_amdgcn_s_sleep(127);  // (test hook: the workers must wait this out)
       for (uint32_t i = threadIdx.x; i < a.tables_words; i += blockDim.x) a.tables[i] = 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -381,8 +381,10 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
             const int pp = 32 * u + bit + 4 * h;         // my first pixel; the second is pp + 1
             const float4 s0 = pd[w][pp], s1 = pd[w][pp + 1];
             const f32x2 Tg = (g == 0) ? f32x2{s0.x, s1.x} : f32x2{s0.w, s1.w};
-            const float dx0 = ex - (bx0 + (float)((rr & 3) + 4 * h));
-            const f32x2 dx = {dx0, dx0 - 1.0f};
+            // (both offsets as ONE subtraction from the exact pixel coordinate, like the forward and the one-pixel form:
+            //  dx0 - 1.0f rounds twice and can differ by an ulp where |dx| crosses a power of two inside the pair)
+            const float px0 = bx0 + (float)((rr & 3) + 4 * h);
+            const f32x2 dx = f32x2{ex, ex} - f32x2{px0, px0 + 1.0f};
             const float dy = ey - (pyu + (float)(rr >> 2));
             const f32x2 power = gauss_power2(cx, cy, cz, dx, dy);
             const f32x2 G = exp2_<FAST>(power);

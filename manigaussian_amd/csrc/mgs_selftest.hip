@@ -99,6 +99,16 @@ __global__ void selftest_kernel(int* result) {
           __float_as_uint(p3.y) != __float_as_uint(gauss_power(cz, -cy, cx, dy, dx0))) bad |= 1 << 29;
     }
   }
+  {  // the pair's pixel offsets: the two-pixel backward forms them as ONE packed subtraction from the exact pixel coordinates,
+     // which must equal the forward's and the one-pixel form's scalar `ex - px` bit for bit -- also where |dx| crosses a power
+     // of two inside the pair and ex - px is inexact (ex in (0, 1), columns 64 / 65, 128 / 129, ...: advisor r5)
+    for (int i = 0; i < 2048; i++) {
+      const float ex = ((float)((lane * 131 + i * 7) % 4093) + 0.5f) * 2.4414062e-4f + (float)(i & 3) * 5.9604645e-8f;  // (0, 1)
+      const float px0 = (float)(((i >> 2) & 1) ? (32 << ((i >> 3) % 3)) : ((lane * 5 + i) % 126));  // 32, 64, 128 or any column
+      const f32x2 dx = f32x2{ex, ex} - f32x2{px0, px0 + 1.0f};
+      if (__float_as_uint(dx.x) != __float_as_uint(ex - px0) || __float_as_uint(dx.y) != __float_as_uint(ex - (px0 + 1.0f))) bad |= 1 << 30;
+    }
+  }
   if (bad) atomicOr(result, bad);
 }
 

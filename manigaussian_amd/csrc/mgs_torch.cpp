@@ -27,6 +27,7 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <deque>
@@ -62,7 +63,7 @@ struct Config {
 Config& cfg() { static Config c; return c; }
 
 struct Counters {
-  std::atomic<int64_t> forwards{0}, backwards{0}, declined{0}, waited{0}, retried{0}, recovered{0};
+  std::atomic<int64_t> forwards{0}, backwards{0}, declined{0}, waited{0}, retried{0}, recovered{0}, budget_fallbacks{0};
 };
 Counters& counters() { static Counters c; return c; }
 
@@ -112,10 +113,13 @@ struct SegClock {
   }
 };
 
-std::atomic<int> g_py_pending{0};  // forwards the Python shim has registered and not read yet (cross-drain hint)
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_py_pending[MAX_DEVICES];  // per device: forwards the Python shim has registered and not read yet (cross-drain hint)
 py::object* g_py_drain = nullptr;  // manigaussian_amd._state: drains the Python side's reports of a device
 
 const char* kOutgrew = "an asynchronous rasterizer forward outgrew the workspace sized from earlier calls of the same shape";
+const char* kHandshake = "an asynchronous rasterizer forward's preprocess gave up waiting for its zeroed tile tables (a workgroup of "
+                         "the launch made no progress for about a second) and binned nothing";
 
 [[noreturn]] void fail(const std::string& what) { throw std::runtime_error(what); }
 
@@ -146,6 +150,10 @@ struct DeviceState {
   std::mutex mu;
   bool python_side_built = false;  // manigaussian_amd._state.DeviceState of this device exists (see rasterize())
   int64_t auto_safe_bytes = 0;     // the default worst-case-workspace budget of this device
+  // bytes of WORST-CASE workspaces that live forwards still hold on this device (a node keeps its workspace until its backward
+  // has run or the graph is freed; the ctypes shim adds its own through hold_add): the `safe` budget is charged against this
+  // sum, not per call -- V forwards before the first backward would otherwise pin V x 4 GB at BASELINE configs[2]
+  std::atomic<int64_t> held_bytes{0};
 
   explicit DeviceState(int idx) : index(idx) {}
 
@@ -178,6 +186,16 @@ struct DeviceState {
   }
 };
 
+// A worst-case workspace charged against its device's budget for as long as somebody holds this object.
+struct Lease {
+  DeviceState* st;
+  int64_t bytes;
+  Lease(DeviceState* s, int64_t b) : st(s), bytes(b) { st->held_bytes += b; }
+  ~Lease() { st->held_bytes -= bytes; }
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+};
+
 std::mutex g_states_mu;
 std::vector<std::unique_ptr<DeviceState>> g_states;
 DeviceState& state(int idx) {
@@ -205,64 +223,87 @@ int poll(PendingRec& p) {
 // appends warnings to `warnings` (issued by the caller outside the lock).
 std::string account(DeviceState& st, PendingRec& p, int rc, std::vector<std::string>* warnings) {
   if (rc == MGS_OK) { st.learn(p.key, p.num_rendered, p.chunks_used, false); return ""; }
-  if (rc == MGS_NEED_CAPACITY) {
-    const int cap = p.a.binning_capacity;
-    const bool over_inst = p.num_rendered > cap && cap > 0;
-    st.learn(p.key, p.num_rendered, -1, !over_inst);
-    std::string what = over_inst ? std::to_string(p.num_rendered) + " (Gaussian, tile) instances > capacity " + std::to_string(cap)
-                                 : "chunk pool of " + std::to_string(p.a.chunk_pool) + " records";
-    std::string msg = std::string(kOutgrew) + " (" + what + "): the images of THAT call were incomplete.  The marks are raised";
+  if (rc == MGS_NEED_CAPACITY || rc == MGS_RETRY_TABLE_INIT) {
+    std::string msg;
+    if (rc == MGS_NEED_CAPACITY) {
+      const int cap = p.a.binning_capacity;
+      const bool over_inst = p.num_rendered > cap && cap > 0;
+      st.learn(p.key, p.num_rendered, -1, !over_inst);
+      std::string what = over_inst ? std::to_string(p.num_rendered) + " (Gaussian, tile) instances > capacity " + std::to_string(cap)
+                                   : "chunk pool of " + std::to_string(p.a.chunk_pool) + " records";
+      msg = std::string(kOutgrew) + " (" + what + "): the images of THAT call were incomplete.  The marks are raised";
+    } else {  // nothing to learn: the scene did not grow, a workgroup of the preprocess launch was held back
+      msg = std::string(kHandshake) + ": the images of THAT call were incomplete";
+    }
     const int policy = cfg().policy.load();
     if (p.recovered || (policy == POLICY_REPAIR && p.recoverable && !p.backward_enqueued)) {
       warnings->push_back(msg + "; the call's backward re-renders on the blocking path before it runs, but a loss computed "
-                                "from those images was computed from incomplete images.  For scenes that grow abruptly use "
-                                "manigaussian_amd.set_forward_mode('safe') (the default) or a larger set_headroom().");
+                                "from those images was computed from incomplete images." +
+                          (rc == MGS_NEED_CAPACITY ? "  For scenes that grow abruptly use manigaussian_amd.set_forward_mode('safe') "
+                                                     "(the default) or a larger set_headroom()."
+                                                   : "  manigaussian_amd.set_options(table_init=1) removes the hand-shake."));
       return "";
     }
     if (p.recoverable && !p.backward_enqueued) {  // overflow policy "raise"
       p.recovered = true;                         // its backward, if it still comes, raises too
-      return msg + "; the step is lost (overflow policy 'raise'): re-run it, or use "
-                   "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.";
+      return msg + "; the step is lost (overflow policy 'raise'): re-run it" +
+             (rc == MGS_NEED_CAPACITY ? ", or use manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly."
+                                      : ".");
     }
-    return msg + " and its gradients were computed on the incomplete state; re-run the step, or use "
-                 "manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly.";
+    return msg + " and its gradients were computed on the incomplete state; re-run the step" +
+           (rc == MGS_NEED_CAPACITY ? ", or use manigaussian_amd.set_forward_mode('safe') (the default) for scenes that grow abruptly."
+                                    : " (manigaussian_amd.set_options(table_init=1) removes the hand-shake).");
   }
   return std::string("rasterizer forward failed: ") + mgs_last_error() + " (code " + std::to_string(rc) + ")";
 }
 
 // Read every report that has arrived (wait: all of them, synchronising with the device once if one is outstanding).
-void drain(DeviceState& st, bool wait) {
+// Three steps, so that the device's mutex is NEVER held across the GIL's release / re-acquisition -- the lock order is GIL ->
+// mutex everywhere (a second Python thread on the same device blocks on the mutex while it holds the GIL): poll under the lock;
+// synchronise outside it; account under the lock again.  `deferred`: append the warnings there instead of issuing them (callers
+// that hold a lock of their own -- a node's -- issue them after dropping it: warn_runtime takes the GIL).
+void drain(DeviceState& st, bool wait, std::vector<std::string>* deferred = nullptr) {
   std::string failed;
   std::vector<std::string> warnings;
+  std::vector<PendingRec*> must_finish;  // reports that were outstanding when the device was synchronised
+  bool need_sync = false;
   {
     std::lock_guard<std::mutex> lk(st.mu);
     if (st.pending.empty()) return;
-    std::deque<std::shared_ptr<PendingRec>> keep;
-    bool synced = false;
     const size_t n = st.pending.size();
+    size_t kept = 0;
     for (size_t i = 0; i < n; i++) {
-      std::shared_ptr<PendingRec> p = st.pending[i];
-      int rc = poll(*p);
-      if (rc == MGS_PENDING && (wait || (n - i - 1) + keep.size() >= (size_t)NSLOTS / 2)) {
-        if (!synced) {  // everything enqueued so far has run after this: a report that is still missing never comes
-          MaybeReleaseGil nogil;
-          c10::hip::HIPGuard g(st.index);
-          (void)hipDeviceSynchronize();
-          synced = true;
-        }
-        rc = poll(*p);
-        if (rc == MGS_PENDING) {
+      PendingRec& p = *st.pending[i];
+      if (poll(p) != MGS_PENDING) continue;
+      if (wait || (n - i - 1) + kept >= (size_t)NSLOTS / 2) { need_sync = true; must_finish.push_back(&p); }
+      else kept++;
+    }
+  }
+  if (need_sync) {  // everything enqueued so far has run after this: a report of must_finish that is still missing never comes
+    MaybeReleaseGil nogil;
+    c10::hip::HIPGuard g(st.index);
+    (void)hipDeviceSynchronize();
+  }
+  {
+    std::lock_guard<std::mutex> lk(st.mu);
+    std::deque<std::shared_ptr<PendingRec>> keep;
+    for (std::shared_ptr<PendingRec>& p : st.pending) {
+      const int rc = poll(*p);
+      if (rc == MGS_PENDING) {
+        if (std::find(must_finish.begin(), must_finish.end(), p.get()) != must_finish.end()) {
           if (failed.empty()) failed = "a rasterizer forward finished without reporting its instance count";
-          continue;
+        } else {
+          keep.push_back(p);  // (enqueued by another thread in the meantime, or not yet due)
         }
+        continue;
       }
-      if (rc == MGS_PENDING) { keep.push_back(p); continue; }
       std::string f = account(st, *p, rc, &warnings);
       if (failed.empty()) failed = f;
     }
     st.pending.swap(keep);
   }
-  for (const std::string& w : warnings) warn_runtime(w);
+  if (deferred) deferred->insert(deferred->end(), warnings.begin(), warnings.end());
+  else for (const std::string& w : warnings) warn_runtime(w);
   if (!failed.empty()) fail(failed);
 }
 
@@ -312,6 +353,7 @@ struct MgsRasterizeBackward : public Node {
   std::vector<SavedVariable> saved;      // the reference's saved inputs: colors, feature, means3D, scales, rotations, cov3D, sh
   at::Tensor opacities, bg, viewmatrix, projmatrix, campos;  // kept alive (the argument struct holds their addresses)
   at::Tensor radii, ws, binning2, grad_buffer;
+  std::shared_ptr<Lease> lease;          // the budget charge of a worst-case workspace (released with `ws`)
   // the images, weakly (they own this node through their grad_fn): a recovery re-renders into them if they still live
   c10::weak_intrusive_ptr<c10::TensorImpl> out_color{c10::intrusive_ptr<c10::TensorImpl>()}, out_feat{c10::intrusive_ptr<c10::TensorImpl>()};
   int device_index = 0;
@@ -327,26 +369,35 @@ struct MgsRasterizeBackward : public Node {
     for (auto& s : saved) s.reset_data();
     saved.clear();
     opacities = bg = viewmatrix = projmatrix = campos = radii = ws = binning2 = grad_buffer = at::Tensor();
+    lease.reset();
     released = true;
   }
   variable_list apply(variable_list&& grads) override;
-  void settle(DeviceState& st, hipStream_t stream);
-  void recover(DeviceState& st, hipStream_t stream);
+  variable_list apply_locked(variable_list&& grads, std::vector<std::string>* warnings);
+  void settle(DeviceState& st, hipStream_t stream, std::vector<std::string>* warnings);
+  void recover(DeviceState& st, hipStream_t stream, bool handshake_only);
 };
 
 // The asynchronous forward of this backward outgrew its workspace and the report is in: bin and render it AGAIN with room
 // (capacity from the count the device reported, worst-case chunk pool: cannot overflow) into the same output tensors, so that the
 // backward runs on a complete state (manigaussian_amd/_C.py recover_forward).
-void MgsRasterizeBackward::recover(DeviceState& st, hipStream_t stream) {
-  const int64_t R = std::max<int64_t>(pending->num_rendered, 0);
-  const int64_t cap = R + R / 4 + 4096;
-  const int Fl = include_feature ? (int)F : 0;
-  const size_t nbytes = mgs_binning_bytes2((int)cap, 0, (int)W, (int)H, Fl);
-  binning2 = at::empty({(int64_t)nbytes}, ws.options());
-  a.binning = binning2.data_ptr();
-  a.binning_bytes = nbytes;
-  a.binning_capacity = (int32_t)cap;
-  a.chunk_pool = 0;
+void MgsRasterizeBackward::recover(DeviceState& st, hipStream_t stream, bool handshake_only) {
+  if (handshake_only) {
+    // the scene did not outgrow anything: a workgroup of the preprocess launch gave up waiting for workgroup 0's zeroed tables.
+    // Same workspace, tables zeroed by a launch of their own this time (no workgroup waits for another).
+    a.opt.set = 1;
+    a.opt.table_init = 1;
+  } else {
+    const int64_t R = std::max<int64_t>(pending->num_rendered, 0);
+    const int64_t cap = R + R / 4 + 4096;
+    const int Fl = include_feature ? (int)F : 0;
+    const size_t nbytes = mgs_binning_bytes2((int)cap, 0, (int)W, (int)H, Fl);
+    binning2 = at::empty({(int64_t)nbytes}, ws.options());
+    a.binning = binning2.data_ptr();
+    a.binning_bytes = nbytes;
+    a.binning_capacity = (int32_t)cap;
+    a.chunk_pool = 0;
+  }
   a.async_forward = 0;
   a.bwd_accum = nullptr;  // the first run's preprocess zeroed the accumulators; nothing touched them since
   a.bwd_accum_bytes = 0;
@@ -384,32 +435,50 @@ void MgsRasterizeBackward::recover(DeviceState& st, hipStream_t stream) {
 }
 
 // Backward entry: what is known about this backward's forward?  (manigaussian_amd/_C.py _settle)
-void MgsRasterizeBackward::settle(DeviceState& st, hipStream_t stream) {
+void MgsRasterizeBackward::settle(DeviceState& st, hipStream_t stream, std::vector<std::string>* warnings) {
   if (!pending) return;
   int rc;
   {
     std::lock_guard<std::mutex> lk(st.mu);
     rc = poll(*pending);
   }
-  if (rc == MGS_NEED_CAPACITY) {
+  if (rc == MGS_NEED_CAPACITY || rc == MGS_RETRY_TABLE_INIT) {
     if (cfg().policy.load() == POLICY_RAISE) {
-      drain(st, false);  // folds the report into the marks and raises ... unless an earlier drain already did
-      fail("the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past the head-room over "
-           "earlier calls of its shape): its images are incomplete and the step is lost; the next call of the shape gets a "
-           "larger workspace (overflow policy 'raise')");
+      drain(st, false, warnings);  // folds the report into the marks and raises ... unless an earlier drain already did
+      fail(rc == MGS_NEED_CAPACITY
+               ? "the asynchronous rasterizer forward of this backward outgrew its workspace (the scene grew past the head-room over "
+                 "earlier calls of its shape): its images are incomplete and the step is lost; the next call of the shape gets a "
+                 "larger workspace (overflow policy 'raise')"
+               : std::string(kHandshake) + ": its images are incomplete and the step is lost (overflow policy 'raise')");
     }
-    drain(st, false);  // learn + warn (this pending is recoverable and its backward has not been enqueued: no raise)
-    recover(st, stream);
+    drain(st, false, warnings);  // learn + warn (this pending is recoverable and its backward has not been enqueued: no raise)
+    recover(st, stream, rc == MGS_RETRY_TABLE_INIT);
     return;
   }
-  if (rc != MGS_OK && rc != MGS_PENDING) drain(st, false);
+  if (rc != MGS_OK && rc != MGS_PENDING) drain(st, false, warnings);
   if (rc == MGS_PENDING) {
     std::lock_guard<std::mutex> lk(st.mu);
     pending->backward_enqueued = true;  // too late to repair: if this forward overflowed, the next drain raises
   }
 }
 
+// The node's mutex is never held while a warning is issued (warn_runtime takes the GIL; a Python thread that holds the GIL may
+// be waiting for this mutex in release_variables): apply_locked collects them, apply issues them after the lock is gone.
 variable_list MgsRasterizeBackward::apply(variable_list&& grads) {
+  std::vector<std::string> warnings;
+  variable_list out;
+  std::exception_ptr err;
+  try {
+    out = apply_locked(std::move(grads), &warnings);
+  } catch (...) {
+    err = std::current_exception();
+  }
+  for (const std::string& w : warnings) warn_runtime(w);
+  if (err) std::rethrow_exception(err);
+  return out;
+}
+
+variable_list MgsRasterizeBackward::apply_locked(variable_list&& grads, std::vector<std::string>* warnings) {
   SegClock clk;
   std::lock_guard<std::mutex> lk(mu);
   TORCH_CHECK(!released, kBackwardTwice);
@@ -431,7 +500,7 @@ variable_list MgsRasterizeBackward::apply(variable_list&& grads) {
   hipStream_t stream = c10::hip::getCurrentHIPStream(device_index).stream();
   DeviceState& st = state(device_index);
   clk.lap(SB_UNPACK);
-  settle(st, stream);
+  settle(st, stream, warnings);
   clk.lap(SB_SETTLE);
   const GradLayout L = grad_layout(P, M, include_feature ? F : 0);
   const bool prezeroed = grad_buffer.defined() && grad_buffer.numel() == L.total;
@@ -515,7 +584,7 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
   clk.lap(SG_STREAM);
   // reports of forwards the Python shim enqueued; and, once per device, the shim's own state (its pinned status ring cannot
   // be allocated later, inside a HIP-graph capture -- which is the shim's job)
-  if (g_py_drain && (g_py_pending.load() > 0 || !st.python_side_built)) {
+  if (g_py_drain && ((di < MAX_DEVICES && g_py_pending[di].load() > 0) || !st.python_side_built)) {
     (*g_py_drain)(di);
     st.python_side_built = true;
   }
@@ -548,16 +617,44 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
                     (int64_t)mgs_binning_bytes2((int)cap_worst, 0, (int)W, (int)H, (int)F) <= safe_bytes;
     wc = WorstCase{P, W, H, F, safe_bytes, ok, cap_worst, ok ? mgs_chunk_pool_max((int)cap_worst, (int)W, (int)H) : 0};
   }
+  // The worst-case workspace is taken only while the worst cases live forwards of this device still hold, plus this one, stay
+  // within the budget (round 5 tested the budget per call: V forwards before the first backward pinned V x 4 GB at
+  // configs[2]) -- and only if the allocator can give it; otherwise the shape goes by its marks, like any shape whose
+  // worst case does not fit (the reference never allocates more than the count needs, rasterize_points.cu:27-33,84-89).
+  const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
+  const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+  const size_t gb = up256(mgs_geom_bytes((int)P, (int)M, (int)W, (int)H)), ib = up256(mgs_img_bytes((int)W, (int)H));
+  const bool want_grad = torch::autograd::compute_requires_grad(means3D, means2D, sh, colors, feat, opacities, scales, rotations, cov3D);
+  at::AutoDispatchBelowADInplaceOrView below_autograd;  // plain tensors from here on; the node is attached by hand
+  at::Tensor ws;
+  std::shared_ptr<Lease> lease;
+  size_t bb = 0;
+  bool worst = mode != MODE_ASYNC && wc.ok;
+  if (worst) {
+    bb = mgs_binning_bytes2((int)wc.cap, (int)wc.pool, (int)W, (int)H, (int)F);
+    if (st.held_bytes.load() + (int64_t)bb > safe_bytes) {
+      worst = false;
+    } else {
+      try {
+        ws = at::empty({(int64_t)(gb + ib + bb)}, u8);
+        if (want_grad) lease = std::make_shared<Lease>(&st, (int64_t)bb);  // (without a backward the workspace dies with this call)
+      } catch (const c10::OutOfMemoryError&) {
+        worst = false;
+        ws = at::Tensor();
+      }
+    }
+    if (!worst) counters().budget_fallbacks++;
+  }
   int64_t cap = 0, pool = 0, mark_R = 0;
-  bool have_guess = wc.ok;
+  bool have_guess = worst;
   {
     std::lock_guard<std::mutex> lk(st.mu);
-    if (wc.ok) { cap = wc.cap; pool = wc.pool; }
+    if (worst) { cap = wc.cap; pool = wc.pool; }
     else have_guess = st.guess(key, &cap, &pool);
     auto it = st.marks.find(key);
     if (it != st.marks.end()) mark_R = it->second.R;
   }
-  const bool lazy = have_guess && (mode == MODE_ASYNC || (mode == MODE_SAFE && wc.ok));
+  const bool lazy = have_guess && (mode == MODE_ASYNC || (mode == MODE_SAFE && worst));
   if (mode == MODE_ASYNC && !lazy) return decline();  // first calls of a shape in async mode: the Python path learns the marks
   if (!lazy) {  // wait for the preprocess: capacity from the marks, worst-case pool for that capacity (cannot overflow)
     cap = mark_R ? mark_R + mark_R / 4 + 4096 : 4 * P + 4096;
@@ -566,13 +663,11 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
   if (cap >= ((int64_t)1 << 31)) return decline();
 
   clk.lap(SG_SIZES);
-  at::AutoDispatchBelowADInplaceOrView below_autograd;  // plain tensors from here on; the node is attached by hand
-  const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
-  const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
   // ONE allocation for the three opaque workspaces [geom | img | binning] (each a multiple of 256 bytes)
-  const size_t gb = up256(mgs_geom_bytes((int)P, (int)M, (int)W, (int)H)), ib = up256(mgs_img_bytes((int)W, (int)H));
-  const size_t bb = mgs_binning_bytes2((int)cap, (int)pool, (int)W, (int)H, (int)F);
-  at::Tensor ws = at::empty({(int64_t)(gb + ib + bb)}, u8);
+  if (!worst) {
+    bb = mgs_binning_bytes2((int)cap, (int)pool, (int)W, (int)H, (int)F);
+    ws = at::empty({(int64_t)(gb + ib + bb)}, u8);
+  }
   at::Tensor out_color, out_feat;
   if (include_feature) {
     at::Tensor out = at::empty({3 + F, H, W}, f32);
@@ -583,7 +678,6 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
     out_feat = at::zeros({1}, f32);  // rasterize_points.cu:71-79: a [1] placeholder
   }
   at::Tensor radii = at::empty({P}, at::TensorOptions().dtype(at::kInt).device(dev));
-  const bool want_grad = torch::autograd::compute_requires_grad(means3D, means2D, sh, colors, feat, opacities, scales, rotations, cov3D);
   at::Tensor grad_buffer;
   GradLayout GL{};
   if (want_grad) {
@@ -662,6 +756,7 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
     for (const at::Tensor* t : {&colors, &feat, &means3D, &scales, &rotations, &cov3D, &sh}) node->saved.emplace_back(*t, false);
     node->opacities = opacities; node->bg = bg; node->viewmatrix = viewmatrix; node->projmatrix = projmatrix; node->campos = campos;
     node->radii = radii; node->ws = ws; node->binning2 = binning2; node->grad_buffer = grad_buffer;
+    node->lease = lease;
     node->out_color = c10::weak_intrusive_ptr<c10::TensorImpl>(out_color.getIntrusivePtr());
     node->out_feat = c10::weak_intrusive_ptr<c10::TensorImpl>(out_feat.getIntrusivePtr());
     torch::autograd::set_history(out_color, node);
@@ -745,7 +840,12 @@ void set_python_drain(py::object fn) {
   delete g_py_drain;
   g_py_drain = fn.is_none() ? nullptr : new py::object(std::move(fn));
 }
-void set_python_pending(int n) { g_py_pending = n; }
+void set_python_pending(int dev, int n) {
+  if (dev >= 0 && dev < MAX_DEVICES) g_py_pending[dev] = n;
+}
+// the ctypes shim's worst-case workspaces are charged against the same per-device sum (manigaussian_amd/_state.py hold())
+int64_t hold_add(int dev, int64_t delta) { return state(dev).held_bytes += delta; }
+int64_t held_bytes(int dev) { return state(dev).held_bytes.load(); }
 
 py::dict profile_read(bool reset) {
   py::dict d;
@@ -761,7 +861,8 @@ py::dict counters_dict(bool reset) {
   py::dict d;
   d["forwards"] = c.forwards.load(); d["backwards"] = c.backwards.load(); d["declined"] = c.declined.load();
   d["waited"] = c.waited.load(); d["retried"] = c.retried.load(); d["recovered"] = c.recovered.load();
-  if (reset) { c.forwards = 0; c.backwards = 0; c.declined = 0; c.waited = 0; c.retried = 0; c.recovered = 0; }
+  d["budget_fallbacks"] = c.budget_fallbacks.load();
+  if (reset) { c.forwards = 0; c.backwards = 0; c.declined = 0; c.waited = 0; c.retried = 0; c.recovered = 0; c.budget_fallbacks = 0; }
   return d;
 }
 
@@ -788,6 +889,8 @@ PYBIND11_MODULE(_mgs_torch, m) {
   m.def("marks_keys", &marks_keys);
   m.def("set_python_drain", &set_python_drain);
   m.def("set_python_pending", &set_python_pending);
+  m.def("hold_add", &hold_add);
+  m.def("held_bytes", &held_bytes);
   m.def("counters", &counters_dict, py::arg("reset") = false);
   m.def("set_profile", [](bool on) { return g_profile.exchange(on); });
   m.def("profile_read", &profile_read, py::arg("reset") = true);

@@ -81,8 +81,10 @@ class _RasterizeViews(torch.autograd.Function):
             guess = st.guess(key)
             T1 = ((W + 15) // 16) * ((H + 15) // 16)
             cap_worst = V * P * T1  # every Gaussian in every tile of every view
-            cannot_overflow = (0 < cap_worst < (1 << 30) and
-                               L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) <= _state.safe_bytes(dev))
+            worst_bytes = L.mgs_views_binning_bytes2(cap_worst, 0, W, H, F, V) if 0 < cap_worst < (1 << 30) else 0
+            # (the budget is charged against the worst cases live forwards of the device still hold: _state.hold)
+            cannot_overflow = (worst_bytes > 0 and worst_bytes <= _state.safe_bytes(dev) and
+                               (_state.forward_mode() == "async" or _state.worst_case_fits(st.index, worst_bytes, dev)))
             if cannot_overflow:
                 guess = (cap_worst, L.mgs_views_chunk_pool_max(cap_worst, W, H, V))
             lazy = guess is not None and _state.lazy_allowed(cannot_overflow) and not s0.prefiltered
@@ -104,6 +106,8 @@ class _RasterizeViews(torch.autograd.Function):
             binning = _EMPTY
             while P > 0:
                 binning = torch.empty((L.mgs_views_binning_bytes2(cap, pool, W, H, F, V),), **u8)
+                if lazy and cannot_overflow and want and cap == cap_worst:
+                    _state.hold(st.index, worst_bytes, binning)
                 _C._fill_args(a, P=P, D=int(s0.sh_degree), M=M, F=F, W=W, H=H, tanfovx=0.0, tanfovy=0.0,
                               scale_modifier=float(s0.scale_modifier), prefiltered=s0.prefiltered, debug=False,
                               include_feature=inc, background=bg, means3D=means3D, sh=sh, colors=colors_precomp,

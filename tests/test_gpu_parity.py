@@ -152,10 +152,10 @@ def test_parity_with_oracle(name, tight):
     _check(CASES[name], tight_bins=tight)
 
 
-_DEFAULTS = dict(gm_waves=12, bin_mode=1, seg=2048, exact_cull=1, fast_exp=0, tight_bins=1)
+_DEFAULTS = dict(gm_waves=12, bin_mode=2, seg=2048, exact_cull=1, fast_exp=0, tight_bins=1)
 VARIANTS = {
-    "binning_tables_in_memory": dict(bin_mode=0),
-    "segments_512": dict(seg=512), "segments_1024": dict(seg=1024), "segments_4096": dict(seg=4096),
+    "binning_tables_in_memory": dict(bin_mode=0), "segment_sort_rank_merge": dict(bin_mode=1),
+    "segments_512": dict(bin_mode=1, seg=512), "segments_1024": dict(bin_mode=1, seg=1024), "segments_4096": dict(bin_mode=1, seg=4096),
     "backward_8_waves": dict(gm_waves=8),
     "backward_16_waves_one_pixel_per_step": dict(gm_waves=16),
     "v_exp_f32_bbox_cull": dict(fast_exp=1, exact_cull=0), "v_exp_f32": dict(fast_exp=1),
@@ -210,10 +210,12 @@ def test_merge_rank_search_over_segment_lengths(seg, P):
     key is ranked in the others by the bounded branch-free search of bin_merge_emit_kernel; the sorted order must be the
     oracle's (images and gradients follow from it)."""
     try:
+        _lib.set_option("bin_mode", 1)  # (the default, bin_mode 2, ranks a tile's keys in one bucket pass: tests/test_binning.py)
         _lib.set_option("seg", seg)
         _check(dict(P=P, F=3, W=16, H=16, neg=False))
     finally:
         _lib.set_option("seg", _DEFAULTS["seg"])
+        _lib.set_option("bin_mode", _DEFAULTS["bin_mode"])
 
 
 def _raw_forward(d, kwd, P, F, W=128, H=128):
@@ -326,7 +328,7 @@ def _train_step(d, rast, dC, dF, between=None):
     return c, f, r, grads
 
 
-@pytest.mark.parametrize("bin_mode", [1, 0], ids=["lds_tables", "tables_in_memory"])
+@pytest.mark.parametrize("bin_mode", [2, 1, 0], ids=["bucket_rank", "lds_tables", "tables_in_memory"])
 def test_async_forward_equals_blocking_forward_and_never_synchronises(bin_mode):
     """(bin_mode 0: the table kernel of the in-memory scatter is the one that reports to the host.)"""
     _lib.set_option("bin_mode", bin_mode)
