@@ -360,6 +360,9 @@ int mgs_selftest(mgs_stream_t stream);
  * validated against exact counts before its numbers for the render kernels are trusted.  sink: >= 256*1024 floats. */
 int mgs_calibration_kernel(int iters, float* sink, mgs_stream_t stream);
 
+/* ... and of the bucket-rank binning (bin_mode 2): 1024 workgroups x 16 stamps (scripts/trace_bin.py). */
+int mgs_debug_read_trace_bin(unsigned long long* host, size_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,7 @@ _EXPORTS = {
                                  [ctypes.POINTER(c_i32)]),
     "mgs_debug_read_trace": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bwd": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
+    "mgs_debug_read_trace_bin": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_selftest": (ctypes.c_int, [c_fp]),
     "mgs_profile_num_stages": (ctypes.c_int, []),
     "mgs_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int]),

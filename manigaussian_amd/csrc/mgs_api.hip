@@ -391,7 +391,7 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
     if (k == 2 && bucket_rank(o, T)) break;  // (the bucket rank of stage 1 wrote the sorted ids)
-    MGS_STAGE(launch_bin_segsort(k, lds, bucket_rank(o, T), g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, status, stream),
+    MGS_STAGE(launch_bin_segsort(k, lds, bucket_rank(o, T), g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, o.dbg, status, stream),
               "binning", a->debug, stream);
   }
   const RenderArgs r = render_args(a, o, g);
@@ -779,7 +779,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   for (int k = 0; k < 3; k++) {
     StageTimer t(ST_BIN_SCATTER + k, stream);
     if (k == 2 && bucket_rank(o, at.T)) break;
-    MGS_HIP(launch_bin_segsort(k, lds, bucket_rank(o, at.T), g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, status, stream),
+    MGS_HIP(launch_bin_segsort(k, lds, bucket_rank(o, at.T), g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, o.dbg, status, stream),
             "binning (views)");
   }
   const RenderArgs r = views_render_args(a, o, at, g);

@@ -547,236 +547,405 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32
 }
 
 // ================================ bucket rank (round 6): ONE launch instead of segment sort + rank merge ==================
-// One workgroup of 1024 threads per tile; the tile's keys never leave the CU between "unsorted slice" and "sorted ids":
-//   1. the slice (<= BK_CAP keys) goes into REGISTERS (<= 16 keys per thread); min / max key of the tile (wave reduce + one
-//      LDS atomic per wave);
-//   2. an ORDER-PRESERVING bucket index per key: the top 24 significant bits of (key - min), scaled to NB buckets (a power of
-//      two between 256 and 4096, about two keys per bucket) -- a monotone function of the 64-bit key, so every key of
-//      bucket b precedes every key of bucket b + 1.  One returning LDS atomic per key counts the bucket and hands the key
-//      its arrival index;
-//   3. exclusive scan of the counts; the keys go to LDS grouped by bucket (start + arrival index);
-//   4. rank inside the bucket = how many of its keys are smaller (keys are unique: depth bits << 32 | id): final position
-//      = bucket start + rank -- the order of a stable sort by (depth bits, id), which is the reference's order
-//      (RAST/cuda_rasterizer/rasterizer_impl.cu:306-320: radix sort of tile << 32 | depth keys, stable in the id);
-//   5. the ids are put in order in LDS and leave with coalesced stores.
-// ~6 barriers and a handful of LDS operations per key against 66 dependent compare-exchange stages + a rank merge.
-// Depth distributions that defeat the buckets (sum of squared bucket counts > 64 per key: thousands of equal depths among
-// spread-out ones) take a bitonic network over the same LDS array instead -- bounded, never wrong.  Slices longer than BK_CAP
-// keys are cut by a coarse first-level histogram into consecutive key ranges of <= BK_CAP keys, each ranked as above (the
-// slice is streamed from L2 once per range); a coarse bucket that alone exceeds BK_CAP keys (more than 16 384 keys of one
-// tile within 1/256 of its depth range) is ranked against the streamed slice directly: slow, correct.
+// `split` workgroups of 1024 threads per tile (the host picks split so that the grid fills the chip: 4 at 64 tiles); the
+// tile's keys never leave the CU between "unsorted slice" and "sorted ids".  Every workgroup of a tile
+//   A. takes the tile's slice into REGISTERS (<= 16 keys per thread; longer slices are re-streamed from L2 instead) and finds
+//      BOUNDS of its keys: min / max of the depth words (32-bit DPP reductions; the index words only if all depths are equal);
+//   B. maps every key to t = the top 24 significant bits of (key - lower bound): a monotone function of the 64-bit key
+//      (depth bits << 32 | id) -- so is floor(t * scale) for any scale > 0, with or without clamping: every key of bucket b
+//      precedes every key of bucket b + 1.  LEVEL 1: 256 such buckets, histogram in LDS, scanned by one wave, which also
+//      cuts THIS workgroup's share out of the sorted order -- the consecutive buckets holding keys [q L / split,
+//      (q + 1) L / split), cut at bucket boundaries -- into rounds of consecutive buckets holding <= 4096 keys;
+//   C. per round, LEVEL 2: the round's keys (still in their registers) onto <= 1024 fine buckets (about four keys each; the
+//      level-1 table serves as the keys' CDF, so the fine buckets follow the depth density): count, scan, a returning LDS atomic on the bucket's start hands out its slots (keys
+//      grouped by bucket in LDS); then every BUCKET's owner thread reads its keys once, ranks them in registers (keys
+//      are unique) and puts their ids in order into an LDS id array, which leaves with coalesced stores.
+// A slice of <= 1024 keys skips level 1 (one workgroup, one round, uniform fine buckets).  The order is that of a stable sort by (depth bits, id):
+// the reference's (RAST/cuda_rasterizer/rasterizer_impl.cu:306-320: radix sort of tile << 32 | depth keys, stable in the id).
+// Rounds 2-5 ran 66 dependent compare-exchange stages + a rank merge.
+// Depth distributions that defeat the buckets are bounded, never wrong: a fine bucket of 5 .. 8 keys is ranked in registers
+// too, 9 .. 64 by a wave (one lane per key); more than that (hundreds of equal depths among spread-out ones) and the round takes
+// a bitonic network over the same LDS array; a level-1 bucket that alone exceeds a round (more than 4096 keys of one tile
+// within 1/256 of its key range) is ranked against the streamed slice directly -- slow, correct.
 constexpr int BK_THREADS = 1024;
-constexpr int BK_KPT = 16;                       // keys per thread
-constexpr int BK_CAP = BK_THREADS * BK_KPT;      // keys one pass holds
-constexpr int BK_NB_MAX = 4096;                  // fine buckets
-constexpr int BK_COARSE = 256;                   // first-level buckets of a slice longer than BK_CAP
+constexpr int BK_KPT = 16;                       // keys a thread keeps in registers
+constexpr int BK_INREG = BK_THREADS * BK_KPT;    // longest slice held in registers
+constexpr int BK_NB1 = 256;                      // level-1 buckets (four per lane of the wave that scans them)
+constexpr int BK_CAP2 = 4096;                    // keys per round
+constexpr int BK_SMALL = 1024;                   // slices up to this length skip level 1 (uniform fine buckets: no CDF)
+constexpr int BK_NB2 = 1024;                     // level-2 buckets (four keys each on average: one owner thread per bucket)
+constexpr uint32_t BK_LOOP_MAX = 64;             // largest fine bucket ranked by comparisons (one lane of a wave per key)
+constexpr int BK_BIG_LIST = 512;                 // fine buckets of 9 .. 64 keys handed to waves per round
 
-struct BkMap { uint64_t kmin; uint32_t shift; float scale; uint32_t nb; };
-__device__ __forceinline__ BkMap bk_map(uint64_t kmin, uint64_t kmax, uint32_t nb) {
+// Phase timeline (diagnostic, MgsOptions.dbg = 256): s_memtime stamps per (workgroup, event), thread 0 / first round only
+constexpr int BK_TRACE_EVENTS = 16;
+__device__ unsigned long long g_bk_trace[1024 * BK_TRACE_EVENTS];
+#define MGS_BKTRACE(ev)                                                                                   \
+  do {                                                                                                    \
+    if (dbg && tid == 0 && blockIdx.x < 1024) g_bk_trace[(size_t)blockIdx.x * BK_TRACE_EVENTS + (ev)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// t(key): the top 24 significant bits of key - kmin (kmin <= every key <= kmax: bounds, not necessarily attained)
+struct BkMap { uint64_t kmin; uint32_t shift, tmax; };
+__device__ __forceinline__ BkMap bk_map(uint64_t kmin, uint64_t kmax) {
   BkMap m;
-  m.kmin = kmin; m.nb = nb;
+  m.kmin = kmin;
   const uint64_t r = kmax - kmin;
   const int bits = r ? 64 - __builtin_clzll(r) : 0;
   m.shift = bits > 24 ? (uint32_t)(bits - 24) : 0u;
-  m.scale = (float)nb / ((float)(uint32_t)(r >> m.shift) + 1.0f);
+  m.tmax = (uint32_t)(r >> m.shift);
   return m;
 }
-__device__ __forceinline__ uint32_t bk_bucket(const BkMap& m, uint64_t key) {
-  const uint32_t t = (uint32_t)((key - m.kmin) >> m.shift);   // < 2^24: exact as a float; monotone in key
-  const uint32_t b = (uint32_t)((float)t * m.scale);          // rounding and truncation keep the order
-  return b < m.nb ? b : m.nb - 1u;
+__device__ __forceinline__ uint32_t bk_t(const BkMap& m, uint64_t key) { return (uint32_t)((key - m.kmin) >> m.shift); }  // < 2^24
+// bucket of t inside the interval [t0, ...] at `scale` buckets per unit, clamped to [0, nb): monotone in t whatever the bounds
+__device__ __forceinline__ uint32_t bk_bucket(uint32_t t, uint32_t t0, float scale, uint32_t nb) {
+  const uint32_t d = t > t0 ? t - t0 : 0u;
+  const uint32_t b = (uint32_t)((float)d * scale);  // d < 2^24: exact as a float; rounding and truncation keep the order
+  return b < nb ? b : nb - 1u;
 }
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v, int lane) {
-  uint64_t o;
-  o = lane_xor64<1>(v, lane); v = o < v ? o : v;
-  o = lane_xor64<2>(v, lane); v = o < v ? o : v;
-  o = lane_xor64<4>(v, lane); v = o < v ? o : v;
-  o = lane_xor64<8>(v, lane); v = o < v ? o : v;
-  o = lane_xor64<16>(v, lane); v = o < v ? o : v;
-  o = lane_xor64<32>(v, lane); v = o < v ? o : v;
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) { return ~wave_umax(~v); }
 
 struct BkShared {
-  uint64_t sk[BK_CAP];            // keys grouped by bucket; later the sorted ids (uint32) in its first half
-  uint32_t cnt[BK_NB_MAX + 1];    // bucket counts -> exclusive starts; cnt[nb] = n
-  uint32_t tmp[192];
-  unsigned long long kmin, kmax;
-  uint32_t total, sumsq, gath;
+  uint64_t sk[BK_CAP2 + 8];       // the round's keys grouped by level-2 bucket (+ 8: an owner reads 8 slots from its start)
+  uint32_t sid[BK_CAP2];          // ... their ids in order
+  uint32_t cnt[BK_NB2 + 1];       // level-2 counts -> exclusive starts -> (after the placement) ends
+  uint32_t c1[BK_NB1 + 1];        // level-1 counts -> exclusive starts; c1[BK_NB1] = L
+  uint32_t rr[2 * BK_NB1];        // this workgroup's rounds: level-1 buckets [rr[2i], rr[2i+1])
+  uint32_t tmp[64];
+  uint32_t biglist[BK_BIG_LIST];  // fine buckets of 9 .. 64 keys, ranked by a wave each
+  uint32_t hmin, hmax, lmin, lmax, nrounds, big, gath, nbig;
 };
 
-// Rank the n <= BK_CAP keys held in registers (key i of thread tid is element tid + 1024 i, i < kpt) and write their ids, in
-// order, to out[0 .. n).  All 1024 threads call it; n and kpt are workgroup-uniform.
-__device__ void bk_rank_emit(BkShared& S, uint64_t (&k)[BK_KPT], uint32_t n, int kpt, uint32_t* __restrict__ out) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  // ---- 1. min / max
-  uint64_t lo = ~0ull, hi = 0ull;
-#pragma unroll
-  for (int i = 0; i < BK_KPT; i++)
-    if (i < kpt && (uint32_t)tid + 1024u * i < n) { lo = k[i] < lo ? k[i] : lo; hi = k[i] > hi ? k[i] : hi; }
-  if (tid == 0) { S.kmin = ~0ull; S.kmax = 0ull; S.sumsq = 0u; }
-  uint32_t nb = 256;
-  while (nb < BK_NB_MAX && 2u * nb <= n) nb <<= 1;   // about two keys per bucket (n / 2 < nb <= n), 256 .. 4096
-  for (uint32_t b = tid; b <= nb; b += BK_THREADS) S.cnt[b] = 0u;
+// Exclusive scan of cnt[0 .. nb) in place (nb a power of two, 256 .. 1024: one count per thread), two barriers; *big is set if
+// a count exceeds BK_LOOP_MAX.  All 1024 threads call it.
+__device__ __forceinline__ void bk_scan(BkShared& S, uint32_t nb, int tid, int lane, int wv) {
+  const uint32_t c = (uint32_t)tid < nb ? S.cnt[tid] : 0u;
+  if (c > BK_LOOP_MAX) S.big = 1u;  // (same value from everybody who writes)
+  const uint32_t incl = wave_incl_scan_add_u32(c);
+  if (lane == 63) S.tmp[wv] = incl;
   __syncthreads();
-  lo = wave_min_u64(lo, lane);
-  hi = ~wave_min_u64(~hi, lane);
-  if (lane == 0) { atomicMin(&S.kmin, (unsigned long long)lo); atomicMax(&S.kmax, (unsigned long long)hi); }
+  // every wave scans the 16 wave totals itself (no third barrier)
+  const uint32_t wt = lane < 16 ? S.tmp[lane] : 0u;
+  const uint32_t wi = wave_incl_scan_add_u32(wt);
+  const uint32_t wave_off = bcast_lane_u32(wi - wt, wv);
+  if ((uint32_t)tid < nb) S.cnt[tid] = wave_off + incl - c;
   __syncthreads();
-  const BkMap m = bk_map(S.kmin, S.kmax, nb);
-  // ---- 2. bucket + arrival index (packed: bucket << 16 | arrival index, n <= 16 384)
-  uint32_t ba[BK_KPT];
-#pragma unroll
-  for (int i = 0; i < BK_KPT; i++) {
-    ba[i] = 0u;
-    if (i < kpt && (uint32_t)tid + 1024u * i < n) {
-      const uint32_t b = bk_bucket(m, k[i]);
-      ba[i] = (b << 16) | atomicAdd(&S.cnt[b], 1u);
-    }
-  }
-  __syncthreads();
-  // ---- 3. skew measure, exclusive scan
-  {
-    uint32_t sq = 0u;
-    for (uint32_t b = tid; b < nb; b += BK_THREADS) { const uint32_t c = S.cnt[b]; sq += c * c; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sq += (uint32_t)__shfl_xor((int)sq, d, 64);
-    if (lane == 0 && sq) atomicAdd(&S.sumsq, sq);
-  }
-  block_exclusive_scan(S.cnt, (int)nb, S.tmp, &S.total);  // (its first barrier orders the reads above before its writes)
-  if (tid == 0) S.cnt[nb] = n;
-  const bool skewed = S.sumsq > 64u * n;  // (S.sumsq is complete: the scan's barriers came after every atomicAdd)
-  if (!skewed) {
-    // ---- 4. keys grouped by bucket; rank inside the bucket
-#pragma unroll
-    for (int i = 0; i < BK_KPT; i++)
-      if (i < kpt && (uint32_t)tid + 1024u * i < n) S.sk[S.cnt[ba[i] >> 16] + (ba[i] & 0xffffu)] = k[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < BK_KPT; i++) {
-      if (i < kpt && (uint32_t)tid + 1024u * i < n) {
-        const uint32_t b = ba[i] >> 16;
-        const uint32_t b0 = S.cnt[b], b1 = S.cnt[b + 1u];
-        uint32_t r = 0u;
-        for (uint32_t j = b0; j < b1; j++) r += S.sk[j] < k[i] ? 1u : 0u;
-        ba[i] = b0 + r;  // the key's final position
-      }
-    }
-    __syncthreads();  // every read of sk is done: its first half becomes the id array
-    uint32_t* sid = reinterpret_cast<uint32_t*>(S.sk);
-#pragma unroll
-    for (int i = 0; i < BK_KPT; i++)
-      if (i < kpt && (uint32_t)tid + 1024u * i < n) sid[ba[i]] = (uint32_t)k[i];
-    __syncthreads();
-    for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = sid[j];
-  } else {
-    // ---- bitonic network over the LDS array (padded to a power of two with ~0)
-    uint32_t n2 = 128;
-    while (n2 < n) n2 <<= 1;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < BK_KPT; i++) {
-      const uint32_t e = (uint32_t)tid + 1024u * i;
-      if (e < n2) S.sk[e] = (i < kpt && e < n) ? k[i] : ~0ull;
-    }
-    for (uint32_t kk = 2; kk <= n2; kk <<= 1)
-      for (uint32_t j = kk >> 1; j >= 1u; j >>= 1) {
-        __syncthreads();
-        for (uint32_t c = tid; c < (n2 >> 1); c += BK_THREADS) {
-          const uint32_t a = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), b = a | j;
-          const uint64_t x = S.sk[a], y = S.sk[b];
-          if ((x > y) == ((a & kk) == 0u)) { S.sk[a] = y; S.sk[b] = x; }
-        }
-      }
-    __syncthreads();
-    for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = (uint32_t)S.sk[j];
-  }
-  __syncthreads();  // LDS is reused by the next range of a long slice
 }
 
-__global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, const uint2* __restrict__ ranges,
+// Rank c <= N keys of one bucket in registers: rank = how many of the others are smaller (unique keys).  Slots >= c hold ~0.
+template <int N>
+__device__ __forceinline__ void bk_owner_sort(BkShared& S, uint32_t b0, uint32_t c) {
+  uint64_t kk[N];
+  uint32_t r[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { kk[i] = (uint32_t)i < c ? S.sk[b0 + i] : ~0ull; r[i] = (uint32_t)(N - 1 - i); }
+  // rank of slot i = (earlier slots that are smaller) + (later slots that are not larger); the padding slots (~0) are larger
+  // than every key, so the ranks of the c keys are a permutation of 0 .. c - 1
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = i + 1; j < N; j++) {
+      const uint32_t lt = kk[i] < kk[j] ? 1u : 0u;
+      r[j] += lt;
+      r[i] -= lt;
+    }
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    if ((uint32_t)i < c) S.sid[b0 + r[i]] = (uint32_t)kk[i];
+}
+
+__global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int split, int dbg, const uint2* __restrict__ ranges,
                                                                      const uint64_t* __restrict__ keys_unsorted,
                                                                      uint32_t* __restrict__ point_list,
                                                                      unsigned long long* hs_fail_mark) {
   __shared__ BkShared S;
-  __shared__ uint32_t coarse[BK_COARSE + 1];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int tile = (int)blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (tile, part): the parts of a tile share the XCD (= blockIdx % 8 under round-robin dispatch) on which the
+  // render kernels read the tile's list (map_block in mgs_render_common.h: tile % 8)
+  const int bid = (int)blockIdx.x;
+  const int tile = (bid / (8 * split)) * 8 + (bid & 7);
+  const uint32_t q = (uint32_t)((bid >> 3) % split);
   // ImgView::ready[1], the preprocess's "a workgroup gave up waiting" mark: every workgroup of the bin scatter has read it
   // (kernel boundary); cleared here so that a replayed HIP graph -- same buffer, same nonce -- does not see a stale failure
   if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;
+  if (dbg && tid < BK_TRACE_EVENTS && blockIdx.x < 1024) g_bk_trace[(size_t)blockIdx.x * BK_TRACE_EVENTS + tid] = 0ull;
   if (tile >= T) return;
+  MGS_BKTRACE(0);
   const uint2 rng = ranges[tile];
   const uint32_t L = rng.y - rng.x;
   if (L == 0u) return;
+  const bool small = L <= (uint32_t)BK_SMALL;   // one workgroup, one round, no level 1
+  if (small && q != 0u) return;
+  MGS_BKTRACE(1);
   const uint64_t* __restrict__ src = keys_unsorted + rng.x;
   uint32_t* __restrict__ dst = point_list + rng.x;
+  const bool inreg = L <= (uint32_t)BK_INREG;   // (workgroup-uniform)
+  const int kpt = inreg ? (int)((L + BK_THREADS - 1) / BK_THREADS) : 0;
   uint64_t k[BK_KPT];
-  if (L <= (uint32_t)BK_CAP) {  // the whole slice in one pass
-    const int kpt = (int)((L + BK_THREADS - 1) / BK_THREADS);
+  uint32_t have = 0u;  // bit i: register slot i holds a key
 #pragma unroll
-    for (int i = 0; i < BK_KPT; i++) {
+  for (int i = 0; i < BK_KPT; i++) {
+    k[i] = ~0ull;
+    if (i < kpt) {  // (uniform)
       const uint32_t e = (uint32_t)tid + 1024u * i;
-      k[i] = (i < kpt && e < L) ? src[e] : ~0ull;
+      if (e < L) { k[i] = src[e]; have |= 1u << i; }
     }
-    bk_rank_emit(S, k, L, kpt, dst);
-    return;
   }
-  // ---- long slice: coarse histogram over the streamed slice -> consecutive key ranges of <= BK_CAP keys
-  uint64_t lo = ~0ull, hi = 0ull;
-  for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint64_t v = src[e]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-  if (tid == 0) { S.kmin = ~0ull; S.kmax = 0ull; }
-  for (int b = tid; b <= BK_COARSE; b += BK_THREADS) coarse[b] = 0u;
-  __syncthreads();
-  lo = wave_min_u64(lo, lane);
-  hi = ~wave_min_u64(~hi, lane);
-  if (lane == 0) { atomicMin(&S.kmin, (unsigned long long)lo); atomicMax(&S.kmax, (unsigned long long)hi); }
-  __syncthreads();
-  const BkMap cm = bk_map(S.kmin, S.kmax, (uint32_t)BK_COARSE);
-  for (uint32_t e = tid; e < L; e += BK_THREADS) atomicAdd(&coarse[bk_bucket(cm, src[e])], 1u);
-  __syncthreads();
-  block_exclusive_scan(coarse, BK_COARSE, S.tmp, &S.total);
-  if (tid == 0) coarse[BK_COARSE] = L;
-  __syncthreads();
-  uint32_t b0 = 0u;
-  while (b0 < (uint32_t)BK_COARSE) {  // (workgroup-uniform: everybody reads the same table)
-    uint32_t b1 = b0 + 1u;
-    while (b1 < (uint32_t)BK_COARSE && coarse[b1 + 1u] - coarse[b0] <= (uint32_t)BK_CAP) b1++;
-    const uint32_t n = coarse[b1] - coarse[b0], first = coarse[b0];
-    if (n == 0u) { b0 = b1; continue; }
-    if (n <= (uint32_t)BK_CAP) {
-      // gather the range's keys into LDS (arrival order), then into registers
-      if (tid == 0) S.gath = 0u;
-      __syncthreads();
-      for (uint32_t e = tid; e < L; e += BK_THREADS) {
-        const uint64_t v = src[e];
-        const uint32_t b = bk_bucket(cm, v);
-        if (b >= b0 && b < b1) S.sk[atomicAdd(&S.gath, 1u)] = v;
-      }
-      __syncthreads();
-      const int kpt = (int)((n + BK_THREADS - 1) / BK_THREADS);
+  // ---- A. bounds of the keys
+  if (tid == 0) { S.hmin = ~0u; S.hmax = 0u; S.lmin = ~0u; S.lmax = 0u; S.nrounds = 0u; S.big = 0u; S.nbig = 0u; }
+  if (tid <= BK_NB1) S.c1[tid] = 0u;
+  S.cnt[tid] = 0u;
+  if (tid == 0) S.cnt[BK_NB2] = 0u;
+  uint32_t hlo = ~0u, hhi = 0u;
+  if (inreg) {
 #pragma unroll
-      for (int i = 0; i < BK_KPT; i++) {
-        const uint32_t e = (uint32_t)tid + 1024u * i;
-        k[i] = (i < kpt && e < n) ? S.sk[e] : ~0ull;
-      }
-      __syncthreads();
-      bk_rank_emit(S, k, n, kpt, dst + first);
+    for (int i = 0; i < BK_KPT; i++)
+      if (i < kpt && ((have >> i) & 1u)) { const uint32_t h = (uint32_t)(k[i] >> 32); hlo = min(hlo, h); hhi = max(hhi, h); }
+  } else {
+    for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint32_t h = (uint32_t)(src[e] >> 32); hlo = min(hlo, h); hhi = max(hhi, h); }
+  }
+  MGS_BKTRACE(2);
+  __syncthreads();
+  hlo = wave_umin(hlo); hhi = wave_umax(hhi);
+  if (lane == 0) { atomicMin(&S.hmin, hlo); atomicMax(&S.hmax, hhi); }
+  __syncthreads();
+  uint64_t kmin = (uint64_t)S.hmin << 32, kmax = ((uint64_t)S.hmax << 32) | 0xffffffffull;
+  if (S.hmin == S.hmax) {  // (uniform; rare) all depths equal: the index words carry the order
+    uint32_t llo = ~0u, lhi = 0u;
+    if (inreg) {
+#pragma unroll
+      for (int i = 0; i < BK_KPT; i++)
+        if (i < kpt && ((have >> i) & 1u)) { llo = min(llo, (uint32_t)k[i]); lhi = max(lhi, (uint32_t)k[i]); }
     } else {
-      // one coarse bucket holds more than BK_CAP keys: rank each of its keys against the streamed slice (slow, correct)
+      for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint32_t v = (uint32_t)src[e]; llo = min(llo, v); lhi = max(lhi, v); }
+    }
+    llo = wave_umin(llo); lhi = wave_umax(lhi);
+    if (lane == 0) { atomicMin(&S.lmin, llo); atomicMax(&S.lmax, lhi); }
+    __syncthreads();
+    kmin = ((uint64_t)S.hmin << 32) | S.lmin; kmax = ((uint64_t)S.hmin << 32) | S.lmax;
+  }
+  MGS_BKTRACE(3);
+  const BkMap m = bk_map(kmin, kmax);
+  const float scale1 = (float)BK_NB1 / ((float)m.tmax + 1.0f);
+  uint32_t nrounds = 1u;
+  if (!small) {
+    // ---- B. level-1 histogram; one wave scans it and cuts out this workgroup's rounds
+    if (inreg) {
+#pragma unroll
+      for (int i = 0; i < BK_KPT; i++)
+        if (i < kpt && ((have >> i) & 1u)) atomicAdd(&S.c1[bk_bucket(bk_t(m, k[i]), 0u, scale1, BK_NB1)], 1u);
+    } else {
+      for (uint32_t e = tid; e < L; e += BK_THREADS) atomicAdd(&S.c1[bk_bucket(bk_t(m, src[e]), 0u, scale1, BK_NB1)], 1u);
+    }
+    __syncthreads();
+    MGS_BKTRACE(4);
+    if (wv == 0) {
+      uint32_t c[4], e[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) c[j] = S.c1[4 * lane + j];
+      const uint32_t sum = c[0] + c[1] + c[2] + c[3];
+      e[0] = wave_incl_scan_add_u32(sum) - sum;
+      e[1] = e[0] + c[0]; e[2] = e[1] + c[1]; e[3] = e[2] + c[2];
+#pragma unroll
+      for (int j = 0; j < 4; j++) S.c1[4 * lane + j] = e[j];
+      if (lane == 0) S.c1[BK_NB1] = L;
+      // this part: [first bucket that starts at or behind q L / split, first bucket at or behind (q + 1) L / split)
+      const uint32_t xlo = (uint32_t)(((uint64_t)q * L) / (uint32_t)split), xhi = (uint32_t)(((uint64_t)(q + 1u) * L) / (uint32_t)split);
+      uint32_t cl = BK_NB1, ch = BK_NB1;
+#pragma unroll
+      for (int j = 3; j >= 0; j--) {
+        if (e[j] >= xlo) cl = 4u * lane + j;
+        if (e[j] >= xhi) ch = 4u * lane + j;
+      }
+      const uint32_t blo = wave_umin(cl);
+      const uint32_t bhi = (q + 1u < (uint32_t)split) ? wave_umin(ch) : (uint32_t)BK_NB1;
+      // rounds: consecutive buckets [r0, r1) holding <= BK_CAP2 keys (at least one bucket)
+      uint32_t r0 = blo, nr = 0u;
+      while (r0 < bhi) {  // (wave-uniform)
+        // first = start of r0: held by lane r0 / 4, slot r0 % 4
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) mine = (4u * lane + j == r0) ? e[j] : mine;
+        const uint32_t first = wave_umax(mine);
+        uint32_t cand = r0 + 1u;  // the largest b in (r0, bhi] whose keys [first, start(b)) fit a round
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t bb = 4u * lane + j;
+          if (bb > r0 && bb <= bhi && e[j] - first <= (uint32_t)BK_CAP2) cand = max(cand, bb);
+        }
+        if (bhi == (uint32_t)BK_NB1 && L - first <= (uint32_t)BK_CAP2) cand = BK_NB1;
+        const uint32_t r1 = wave_umax(cand);
+        if (lane == 0) { S.rr[2u * nr] = r0; S.rr[2u * nr + 1u] = r1; }
+        nr++;
+        r0 = r1;
+      }
+      if (lane == 0) S.nrounds = nr;
+    }
+    __syncthreads();
+    nrounds = S.nrounds;
+    MGS_BKTRACE(5);
+  }
+  for (uint32_t rd = 0; rd < nrounds; rd++) {  // (workgroup-uniform)
+    const uint32_t r0 = small ? 0u : S.rr[2u * rd], r1 = small ? (uint32_t)BK_NB1 : S.rr[2u * rd + 1u];
+    const uint32_t first = small ? 0u : S.c1[r0];
+    const uint32_t n = small ? L : S.c1[r1] - first;
+    if (rd > 0u) {  // (the first round's tables were zeroed in the prologue)
+      __syncthreads();
+      S.cnt[tid] = 0u;
+      if (tid == 0) { S.cnt[BK_NB2] = 0u; S.big = 0u; S.nbig = 0u; }
+      __syncthreads();
+    }
+    if (n == 0u) continue;
+    uint32_t* __restrict__ out = dst + first;
+    if (n > (uint32_t)BK_CAP2) {
+      // one level-1 bucket holds more than a round: rank each of its keys against the streamed slice (slow, correct)
       for (uint32_t e = tid; e < L; e += BK_THREADS) {
         const uint64_t v = src[e];
-        if (bk_bucket(cm, v) != b0) continue;
+        if (bk_bucket(bk_t(m, v), 0u, scale1, BK_NB1) != r0) continue;
         uint32_t r = 0u;
         for (uint32_t j = 0; j < L; j++) {
           const uint64_t u = src[j];
-          r += (u < v && bk_bucket(cm, u) == b0) ? 1u : 0u;
+          r += (u < v && bk_bucket(bk_t(m, u), 0u, scale1, BK_NB1) == r0) ? 1u : 0u;
         }
-        dst[first + r] = (uint32_t)v;
+        out[r] = (uint32_t)v;
       }
+      continue;
     }
-    b0 = b1;
+    // ---- C. level 2.  Fine bucket of a key: the level-1 table is the keys' CDF at 256 points; inside a level-1 bucket its keys
+    //         are spread linearly over as many fine buckets as the bucket has keys -- about one key per fine bucket wherever
+    //         the depth density goes up or down inside the tile.  Monotone: level-1 buckets are ordered, and inside one the
+    //         fraction of t * scale1 is.  (A slice without level 1: the t interval onto nb uniform buckets.)
+    // Four keys per fine bucket on average: ONE owner thread per bucket ranks its <= 8 keys in registers in one batch (a
+    // bucket per key costs four dependent passes per thread).
+    uint32_t nb = 256;
+    while (4u * nb < n) nb <<= 1;   // n / 4 <= nb < n / 2 (or 256): 256 .. 1024
+    const float scale2 = (float)nb / ((float)m.tmax + 1.0f);
+    // a slice that is not in registers is streamed and the round's keys take the first four register slots in arrival order
+    uint32_t inr = have;
+    if (!inreg) {
+      inr = 0u;
+      if (tid == 0) S.gath = 0u;
+      __syncthreads();
+      for (uint32_t e0 = 0; e0 < L; e0 += BK_THREADS) {
+        const uint32_t e = e0 + (uint32_t)tid;
+        const uint64_t v = e < L ? src[e] : ~0ull;
+        const uint32_t b = e < L ? bk_bucket(bk_t(m, v), 0u, scale1, BK_NB1) : 0xffffffffu;
+        if (b >= r0 && b < r1) S.sk[atomicAdd(&S.gath, 1u)] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t e = (uint32_t)tid + 1024u * i;
+        k[i] = ~0ull;
+        if (e < n) { k[i] = S.sk[e]; inr |= 1u << i; }
+      }
+      __syncthreads();
+    }
+    uint32_t pk[BK_KPT / 2];  // the keys' fine buckets, two per register (0xffff: not a key of this round)
+#pragma unroll
+    for (int i = 0; i < BK_KPT / 2; i++) pk[i] = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++)
+      if ((inr >> i) & 1u) {
+        const uint32_t t = bk_t(m, k[i]);
+        uint32_t b2 = 0xffffu;
+        if (small) {
+          b2 = bk_bucket(t, 0u, scale2, nb);
+        } else {
+          const float x = (float)t * scale1;
+          uint32_t b1 = (uint32_t)x;
+          b1 = b1 < (uint32_t)BK_NB1 ? b1 : (uint32_t)BK_NB1 - 1u;  // (= bk_bucket(t, 0, scale1, BK_NB1): the histogram's bucket)
+          if (b1 >= r0 && b1 < r1) {
+            const uint32_t st = S.c1[b1], c = S.c1[b1 + 1u] - st;  // c >= 1: this key is one of them
+            const uint32_t j = (uint32_t)((x - (float)b1) * (float)c);
+            b2 = (st - first + (j < c ? j : c - 1u)) >> 2;
+          }
+        }
+        if (b2 != 0xffffu) {
+          atomicAdd(&S.cnt[b2], 1u);
+          pk[i >> 1] = (i & 1) ? ((pk[i >> 1] & 0x0000ffffu) | (b2 << 16)) : ((pk[i >> 1] & 0xffff0000u) | b2);
+        }
+      }
+    __syncthreads();
+    if (rd == 0u) MGS_BKTRACE(8);
+    bk_scan(S, nb, tid, lane, wv);
+    if (rd == 0u) MGS_BKTRACE(9);
+    const bool skewed = S.big != 0u;
+    // the keys go to LDS grouped by bucket: a returning atomic on the bucket's START hands out its slots, so that afterwards
+    // cnt[b] is the END of bucket b (= the start of b + 1) -- no arrival index is kept in registers
+    uint32_t n2 = 128;
+    if (skewed) {
+      while (n2 < n) n2 <<= 1;
+      for (uint32_t e = n + tid; e < n2; e += BK_THREADS) S.sk[e] = ~0ull;  // padding of the bitonic network below
+    }
+#pragma unroll
+    for (int i = 0; i < BK_KPT; i++) {
+      const uint32_t b2 = (pk[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+      if (b2 != 0xffffu) S.sk[atomicAdd(&S.cnt[b2], 1u)] = k[i];
+    }
+    __syncthreads();
+    if (rd == 0u) MGS_BKTRACE(10);
+    if (!skewed) {
+      // every bucket's owner ranks its keys (each key is read once)
+      if ((uint32_t)tid < nb) {  // (whole waves: nb is a multiple of 64)
+        const uint32_t b = (uint32_t)tid;
+        const uint32_t b0 = b ? S.cnt[b - 1u] : 0u, c = S.cnt[b] - b0;
+        if (ballot(c > 4u) == 0ull) {
+          bk_owner_sort<4>(S, b0, c);
+        } else if (c <= 8u) {
+          bk_owner_sort<8>(S, b0, c);
+        } else {
+          // 9 .. 64 keys (the depth density peaks here): handed to a whole WAVE below -- one lane per key, c broadcast
+          // reads each -- instead of c^2 reads by this one thread
+          const uint32_t slot = atomicAdd(&S.nbig, 1u);
+          if (slot < (uint32_t)BK_BIG_LIST) {
+            S.biglist[slot] = b;
+          } else {
+            for (uint32_t i = 0; i < c; i++) {
+              const uint64_t v = S.sk[b0 + i];
+              uint32_t r = 0u;
+              for (uint32_t j = 0; j < c; j++) r += S.sk[b0 + j] < v ? 1u : 0u;
+              S.sid[b0 + r] = (uint32_t)v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const uint32_t nbig = min(S.nbig, (uint32_t)BK_BIG_LIST);
+        for (uint32_t w = (uint32_t)wv; w < nbig; w += BK_THREADS / 64) {  // (wave-uniform)
+          const uint32_t b = S.biglist[w];
+          const uint32_t b0 = b ? S.cnt[b - 1u] : 0u, c = S.cnt[b] - b0;  // c <= BK_LOOP_MAX = 64 lanes
+          const uint64_t v = (uint32_t)lane < c ? S.sk[b0 + lane] : ~0ull;
+          const uint32_t vlo = (uint32_t)v, vhi = (uint32_t)(v >> 32);
+          uint32_t r = 0u;
+          for (uint32_t j = 0; j < c; j++) {  // key j, broadcast from lane j (scalar registers: no LDS round trip per step)
+            const uint64_t u = ((uint64_t)bcast_lane_u32(vhi, (int)j) << 32) | bcast_lane_u32(vlo, (int)j);
+            r += u < v ? 1u : 0u;
+          }
+          if ((uint32_t)lane < c) S.sid[b0 + r] = (uint32_t)v;
+        }
+        if (nbig) __syncthreads();  // (workgroup-uniform)
+      }
+      if (rd == 0u) MGS_BKTRACE(11);
+      for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = S.sid[j];
+      if (rd == 0u) MGS_BKTRACE(12);
+    } else {
+      // ---- bitonic network over the LDS array (padded to a power of two with ~0 above)
+      for (uint32_t kk = 2; kk <= n2; kk <<= 1)
+        for (uint32_t j = kk >> 1; j >= 1u; j >>= 1) {
+          for (uint32_t c = tid; c < (n2 >> 1); c += BK_THREADS) {
+            const uint32_t a = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), b = a | j;
+            const uint64_t x = S.sk[a], y = S.sk[b];
+            if ((x > y) == ((a & kk) == 0u)) { S.sk[a] = y; S.sk[b] = x; }
+          }
+          __syncthreads();
+        }
+      for (uint32_t j = tid; j < n; j += BK_THREADS) out[j] = (uint32_t)S.sk[j];
+    }
   }
+  MGS_BKTRACE(15);
 }
 
 template <int SEGN>
@@ -796,7 +965,7 @@ static void launch_sort_or_merge(int which, const BinView& b, const ImgView& im,
 }
 
 hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const GeomView& g, const BinView& b, const ImgView& im, int Pg,
-                              int V, int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s) {
+                              int V, int capacity, int tiles_x, int tiles_y, int seg, int dbg, StatusSink status, hipStream_t s) {
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
@@ -819,9 +988,16 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
     return hipGetLastError();
   }
   if (bucket) {  // which == 1: the bucket rank does the work of segment sort + rank merge; which == 2: nothing left to do
-    if (which == 1)
-      hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(T), dim3(BK_THREADS), 0, s, T, im.ranges, b.keys_unsorted, b.point_list,
-                         im.ready ? im.ready + 1 : nullptr);
+    if (which == 1) {
+      // parts per tile: enough workgroups to fill the chip (two of them fit a CU), a power of two <= 8.  (seg, which this
+      // binning has no use for, overrides it for experiments: 512 -> 1, 1024 -> 2, 4096 -> 8.)
+      int split = 1;
+      while (split < 8 && T * split * 2 <= 256) split *= 2;
+      if (seg == 512) split = 1; else if (seg == 1024) split = 2; else if (seg == 4096) split = 8;
+      const int grid = ((T + 7) / 8) * 8 * split;
+      hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(grid), dim3(BK_THREADS), 0, s, T, split, dbg & 256, im.ranges, b.keys_unsorted,
+                         b.point_list, im.ready ? im.ready + 1 : nullptr);
+    }
     return hipGetLastError();
   }
   switch (seg) {
@@ -834,3 +1010,9 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
 }
 
 }  // namespace mgs
+
+// diagnostic: copy the bucket rank's phase timeline out (count = 1024 * 16 uint64)
+extern "C" int mgs_debug_read_trace_bin(unsigned long long* host, size_t count) {
+  const size_t n = sizeof(mgs::g_bk_trace) / sizeof(unsigned long long);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mgs::g_bk_trace), (count < n ? count : n) * sizeof(unsigned long long));
+}

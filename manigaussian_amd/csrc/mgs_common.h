@@ -253,7 +253,7 @@ unsigned long long next_nonce();  // process-wide counter (never 0) mixed with a
 // one-workgroup table kernel + a scatter with one atomic per instance on cursors in memory (any tile count).
 // bucket: stage 1 is the one-launch bucket rank (mgs_binning.hip, round 6) and stage 2 is empty, instead of segment sort + rank merge
 hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const GeomView& g, const BinView& b, const ImgView& im, int Pg,
-                              int V, int capacity, int tiles_x, int tiles_y, int seg, StatusSink status, hipStream_t s);
+                              int V, int capacity, int tiles_x, int tiles_y, int seg, int dbg, StatusSink status, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, const float* proj,
                                uint8_t* present, hipStream_t s);
 

@@ -265,7 +265,10 @@ std::string account(DeviceState& st, PendingRec& p, int rc, std::vector<std::str
 void drain(DeviceState& st, bool wait, std::vector<std::string>* deferred = nullptr) {
   std::string failed;
   std::vector<std::string> warnings;
-  std::vector<PendingRec*> must_finish;  // reports that were outstanding when the device was synchronised
+  // reports that were outstanding when the device was synchronised.  Shared pointers, not addresses: another thread's drain may
+  // account and free a record in the meantime, and a forward enqueued AFTER the synchronisation may be allocated at that very
+  // address -- it would pass for "must have reported" (found by the two-thread stress test)
+  std::vector<std::shared_ptr<PendingRec>> must_finish;
   bool need_sync = false;
   {
     std::lock_guard<std::mutex> lk(st.mu);
@@ -273,9 +276,9 @@ void drain(DeviceState& st, bool wait, std::vector<std::string>* deferred = null
     const size_t n = st.pending.size();
     size_t kept = 0;
     for (size_t i = 0; i < n; i++) {
-      PendingRec& p = *st.pending[i];
-      if (poll(p) != MGS_PENDING) continue;
-      if (wait || (n - i - 1) + kept >= (size_t)NSLOTS / 2) { need_sync = true; must_finish.push_back(&p); }
+      const std::shared_ptr<PendingRec>& p = st.pending[i];
+      if (poll(*p) != MGS_PENDING) continue;
+      if (wait || (n - i - 1) + kept >= (size_t)NSLOTS / 2) { need_sync = true; must_finish.push_back(p); }
       else kept++;
     }
   }
@@ -290,7 +293,7 @@ void drain(DeviceState& st, bool wait, std::vector<std::string>* deferred = null
     for (std::shared_ptr<PendingRec>& p : st.pending) {
       const int rc = poll(*p);
       if (rc == MGS_PENDING) {
-        if (std::find(must_finish.begin(), must_finish.end(), p.get()) != must_finish.end()) {
+        if (std::find(must_finish.begin(), must_finish.end(), p) != must_finish.end()) {
           if (failed.empty()) failed = "a rasterizer forward finished without reporting its instance count";
         } else {
           keep.push_back(p);  // (enqueued by another thread in the meantime, or not yet due)

