@@ -146,24 +146,30 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds):
-    """Oracle B fwd+bwd on the host cores (the checker, timed beside the GPU path; never the product)."""
+def cpu_baseline(syn, sc, cam, d_color, d_feat, P, max_seconds, threads=None, max_passes=5):
+    """Oracle B fwd+bwd on the host cores (the checker, timed beside the GPU path; never the product).  threads: OpenMP threads
+    (None: all the host has)."""
     from oracle import oracle_b
     oracle_b.build()
     st = types.SimpleNamespace(**syn.camera_settings_kwargs(cam, 1, True))
-    cores = oracle_b.max_threads()
-    times = []
-    t_start = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        _, _, _, state = oracle_b.forward(sc["means3D"], sc["opacities"], st, shs=sc["shs"],
-                                          language_feature=sc["language_feature"], scales=sc["scales"],
-                                          rotations=sc["rotations"])
-        oracle_b.backward(state, d_color, d_feat)
-        times.append(time.perf_counter() - t0)
-        del state
-        if len(times) >= 5 or time.perf_counter() - t_start > max_seconds:
-            break
+    all_cores = oracle_b.max_threads()
+    cores = all_cores if threads is None else min(int(threads), all_cores)
+    oracle_b.set_threads(cores)
+    try:
+        times = []
+        t_start = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            _, _, _, state = oracle_b.forward(sc["means3D"], sc["opacities"], st, shs=sc["shs"],
+                                              language_feature=sc["language_feature"], scales=sc["scales"],
+                                              rotations=sc["rotations"])
+            oracle_b.backward(state, d_color, d_feat)
+            times.append(time.perf_counter() - t0)
+            del state
+            if len(times) >= max_passes or time.perf_counter() - t_start > max_seconds:
+                break
+    finally:
+        oracle_b.set_threads(all_cores)
     best = min(times)
     return {"value": P / best, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} fwd+bwd passes of the same workload (1 view), best of {len(times)}: "
@@ -231,7 +237,7 @@ def lib_hash():
 def counter_files(cfg_name, views):
     """Committed counter passes for this workload (scripts/gpu_round4.sh writes them), newest round first."""
     suffix = "" if (cfg_name == "c3" and views == 1) else f"_{cfg_name}" + (f"_v{views}" if views > 1 else "")
-    return [f"r{r:02d}_sq_counters{suffix}.json" for r in (5, 4, 3, 2)]
+    return [f"r{r:02d}_sq_counters{suffix}.json" for r in (6, 5, 4, 3, 2)]
 
 
 def committed_counters(kernel_substr, build_id, files):
@@ -257,16 +263,19 @@ def committed_counters(kernel_substr, build_id, files):
 
 
 # kernel (stage-timer name, substring of the kernel's symbol, label)
-KERNELS = [("preprocess_fwd", "preprocess_fwd_kernel", "K2 forward preprocess"),
-           ("bin_scatter", "bin_scatter_kernel", "K4' bin scatter"),
-           ("bin_segsort", "bin_segsort_kernel", "K5' segment sort"),
-           ("bin_merge", "bin_merge_emit_kernel", "K6' rank merge + emit"),
-           ("render_fwd", "coop_fwd_pairs_kernel", "K7 render forward"),
-           ("render_bwd", "gm_bwd_kernel", "K8 render backward"),
-           ("preprocess_bwd", "preprocess_bwd_kernel", "K9+K10 backward preprocess")]
+KERNELS_SEGSORT = [("preprocess_fwd", "preprocess_fwd_kernel", "K2 forward preprocess"),
+                   ("bin_scatter", "bin_scatter_kernel", "K4' bin scatter"),
+                   ("bin_segsort", "bin_segsort_kernel", "K5' segment sort"),
+                   ("bin_merge", "bin_merge_emit_kernel", "K6' rank merge + emit"),
+                   ("render_fwd", "coop_fwd_pairs_kernel", "K7 render forward"),
+                   ("render_bwd", "gm_bwd_kernel", "K8 render backward"),
+                   ("preprocess_bwd", "preprocess_bwd_kernel", "K9+K10 backward preprocess")]
+# bin_mode 2 (the default since round 6): ONE bucket-rank launch in the segment sort's stage slot, no merge launch
+KERNELS_BUCKET = [k for k in KERNELS_SEGSORT if k[0] not in ("bin_segsort", "bin_merge")]
+KERNELS_BUCKET.insert(2, ("bin_segsort", "bin_bucket_emit_kernel", "K5'' bucket rank + emit (one launch; stage slot of the segment sort)"))
 
 
-def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk):
+def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk, bucket=True):
     """HBM bytes ONE launch of each kernel has to move in THIS dataflow, every array once: P Gaussians, V views
     per launch (Pv = V P virtual Gaussians), nvis = sum over the views of Gaussians with radii > 0, R = (Gaussian, tile)
     instances, inc = (8x8 block, Gaussian) incidences of the chunks some pixel visited, pixel_chunks = (pixel, 64-survivor chunk)
@@ -282,8 +291,8 @@ def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk):
     return {
         "preprocess_fwd": Pv * 12 + nvis * (28 + 4 + 12 * M) + Pv * 16 + nvis * (4 + 32 + 12 + 24 + 1) + zero,
         "bin_scatter": Pv * 12 + nblk * T * 4 + R * 8,
-        "bin_segsort": R * 8 + R * 8,
-        "bin_merge": R * 8 + R * 4,
+        "bin_segsort": (R * 8 + R * 4) if bucket else (R * 8 + R * 8),   # bucket rank: keys in, sorted ids out
+        "bin_merge": 0 if bucket else (R * 8 + R * 4),
         "render_fwd": R * 4 + nvis * rec + inc * 4 + state + npix * (4 * (3 + F) + 8),
         "render_bwd": inc * 4 + nvis * rec + state + npix * (4 * (3 + F) + 8) + nvis * (32 + 12 + 4 * F),
         "preprocess_bwd": Pv * 4 + nvis * (12 + 28 + 12 * M + 24 + 1 + 32 + 12) + Pv * 12 + P * (4 + 12 + 24 + 12 * M + 12 + 16),
@@ -739,10 +748,12 @@ def main():
         npix = W * H * launch_views  # pixels one launch covers
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16) * launch_views
         nblk = launch_views * ((P + 1023) // 1024)
-        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk)
+        bucket = _lib.get_option("bin_mode") == 2 and T_tiles <= 4096
+        KERNELS = KERNELS_BUCKET if bucket else KERNELS_SEGSORT
+        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk, bucket)
         so_hash = lib_hash()
         cfiles = counter_files(args.config, launch_views if not deform else 1) if not deform else \
-            [f"r05_sq_counters_{args.config}.json", f"r04_sq_counters_{args.config}.json"]
+            [f"r06_sq_counters_{args.config}.json", f"r05_sq_counters_{args.config}.json", f"r04_sq_counters_{args.config}.json"]
         violations = []
 
         def hbm_line(stage, substr, label):
@@ -800,7 +811,7 @@ def main():
                     "numbers stay comparable"}
         roof_fwd = dict(by_kernel["render_fwd"], kernel="K7 render forward (coop_fwd_pairs_kernel)")
         roof_fwd["limiter"] = limiter("render_fwd")
-        path_model = sum(mb.values()) * launches_per_step
+        path_model = sum(mb[k] for k, _, _ in KERNELS) * launches_per_step
         path_traffic = None
         if all(by_kernel[k]["traffic"] for k in by_kernel):
             path_traffic = sum(by_kernel[k]["traffic"] for k in by_kernel) * launches_per_step
@@ -833,6 +844,7 @@ def main():
                        "visible_gaussians_per_launch": nvis, "block_gaussian_incidences_per_launch": incidences,
                        "chunks_per_launch": chunks, "pixel_chunks_per_launch": pixel_chunks,
                        "tight_bins": _lib.get_option("tight_bins"), "fast_exp": _lib.get_option("fast_exp"),
+                       "bin_mode": _lib.get_option("bin_mode"),
                        "deformation": ("DeformationField per timestep: HIP input assembly -> fp32 MLP 70->512x5->7 (torch GEMMs, "
                                        "fused HIP elementwise passes) -> HIP apply; gradients of the MLP parameters (one flat "
                                        "bucket) and of point_latent") if deform else None,
@@ -877,14 +889,14 @@ def main():
                          "frac_of_peak_by_counter_bytes": (path_traffic / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if path_traffic and rast_ms > 0 else None,
                          "survey_8d_bytes_per_step_per_gpu": s8d_path,
-                         "note": "the rasterizer's seven kernels: model bytes (every array once, DESIGN.md 4) over the sum of "
+                         "note": "the rasterizer's kernels (six with the bucket-rank binning, seven with segment sort + merge): model bytes (every array once, DESIGN.md 4) over the sum of "
                                  "their launch durations; SURVEY.md 8d's figure (per-instance atomics charged) beside it"
                                  + ("; the deformation MLP's GEMMs are MFMA work: roofline_mlp" if deform else "")},
             "roofline_check": {"all_fractions_le_1": not violations, "violations": violations or None},
             "stages_ms": stages,
             "stages_note": "hipEvent pairs around each launch (mgs_set_option('profile', 2)): a pair reads ~2 us longer than "
                            "rocprofv3's kernel duration for the same launch, so their sum exceeds ms_per_step; the committed "
-                           "profiles/r05_rocprofv3_kernel_stats_*.csv carry the kernel durations",
+                           "profiles/r06_rocprofv3_kernel_stats_*.csv carry the kernel durations",
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             if deform:
@@ -892,11 +904,21 @@ def main():
                                                            renders_total, args.cpu_seconds * 2)
             else:
                 out["cpu_baseline"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds)
+                # SURVEY.md 8d's protocol: the same port on 8 threads and on 1 beside all the host's cores (bounded: ~10 s each)
+                out["cpu_baseline_threads8"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds * 0.6,
+                                                            threads=8, max_passes=3)
+                out["cpu_baseline_threads1"] = cpu_baseline(syn, sc, cam, d_color_h, d_feat_h, P, args.cpu_seconds * 0.6,
+                                                            threads=1, max_passes=2)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-            if not deform and not args.no_reference_kernels:
-                out["reference_kernels_same_gpu"] = reference_kernels(syn, sc, cam, d_color_h, d_feat_h, P, F, value)
         else:
             out["cpu_baseline"] = None
+        if n_gpus == 1 and not deform and not args.no_reference_kernels:  # (independent of --no-cpu-baseline: it runs on the GPU)
+            out["reference_kernels_same_gpu"] = reference_kernels(syn, sc, cam, d_color_h, d_feat_h, P, F, value)
+        # the LAST keys of the line are the ones a truncated tail still shows: what every mode measured, the package default
+        # ("eager-safe": what an unmodified caller gets) first
+        out["headline_mode"] = mode
+        out["ms_per_step_package_default"] = out["modes_ms_per_step"].get("eager-safe")
+        out["modes_ms_per_step"] = out.pop("modes_ms_per_step")
         print(json.dumps(out))
         if violations:
             print("bench.py: roofline fraction above 1: " + "; ".join(violations), file=sys.stderr)

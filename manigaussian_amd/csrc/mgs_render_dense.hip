@@ -381,7 +381,10 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
           for (int s = 0; s < BD; s++) load_B(s);
         }
-        float alive = live ? 1.0f : 0.0f;  // 0 once the pixel has terminated (kept in a VGPR: no scalar mask algebra per entry)
+        // The walking transmittance Tc is zeroed when the pixel terminates: from then on every test_T is 0 < 1e-4, i.e. every later
+        // entry "terminates" again and is not blended -- no separate alive flag, and the chain per entry is sub, mul, compare,
+        // select (rounds 3-4: seven dependent instructions).  T keeps the value the reference's loop breaks with.
+        float Tc = live ? T : 0.f;
         uint32_t last = 0;
         float Tm = T;  // transmittance entering the chunk's second group of 32
         bool stop = false;  // wave-uniform: the chunk is exhausted or every pixel has terminated
@@ -389,7 +392,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
 #pragma unroll
         for (int g = 0; g < NSTEP / GS; g++) {
           if (g * GS == NSTEP / 2) Tm = T;
-          stop = stop || (uint32_t)(2 * g * GS) >= n_my || ballot(alive != 0.f) == 0;
+          stop = stop || (uint32_t)(2 * g * GS) >= n_my || ballot(Tc != 0.f) == 0;
           __builtin_amdgcn_sched_barrier(0);
           if (!stop) {
             f32x2 a2q = {0.f, 0.f};  // the second chunk's alphas of a double step (evaluated at its even step)
@@ -406,12 +409,11 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
               const float aa[2] = {a0, a1};
 #pragma unroll
               for (int u = 0; u < 2; u++) {
-                const float test_T = T * (1.0f - aa[u]);
+                const float test_T = Tc * (1.0f - aa[u]);
                 const bool term = test_T < 0.0001f;
-                const float a = (term ? 0.f : aa[u]) * alive;  // the entry's alpha if it is blended for this pixel, else 0
-                alive = term ? 0.f : alive;
-                wq[u] = a * T;
-                T = T * (1.0f - a);
+                wq[u] = (term ? 0.f : aa[u]) * Tc;   // alpha T if the entry is blended for this pixel, else 0
+                Tc = term ? 0.f : test_T;            // (= T (1 - alpha), the same rounding)
+                T = term ? T : test_T;
                 last = wq[u] > 0.f ? (uint32_t)(2 * s + u) + 1u : last;
               }
               const float wk = k ? wq[1] : wq[0];  // the weight of MY entry

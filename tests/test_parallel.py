@@ -218,15 +218,18 @@ def _dyn_worker(rank, world, port, out_dir, P, T, V):
     bucket = GradBucket(dict(field.named_parameters()))
     _dyn_step(plan, sc, field, latent_local, zf[lo:hi], actions, views, bucket)
     torch.save(dict(lo=lo, hi=hi, timesteps=plan.timesteps, views=plan.views, latent_grad=latent_local.grad,
+                    world_size_seen=dist.get_world_size(), group_size=plan.group_size,
                     params={k: p.grad.clone() for k, p in field.named_parameters()}, desc=plan.describe(P)),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,T,V,P", [(2, 1, 4, 151), (4, 2, 2, 96), (2, 2, 2, 80)],
-                         ids=["c5-like:2ranks-share-1-timestep", "4ranks-2groups", "c4-like:1-timestep-per-rank"])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,T,V,P", [(2, 1, 4, 151), (4, 2, 2, 96), (2, 2, 2, 80), (8, 1, 8, 93), (8, 4, 4, 70)],
+                         ids=["c5-like:2ranks-share-1-timestep", "4ranks-2groups", "c4-like:1-timestep-per-rank",
+                              "configs[4]-on-8:all-8-ranks-share-the-timestep-P-not-divisible",
+                              "configs[3]-on-8:2-ranks-per-timestep-2-views-each"])
 def test_point_sharded_deformation_equals_the_single_process_step(tmp_path, world, T, V, P):
     """parallel.sharded_deformation + DynamicPlan: ranks that share a timestep split its MLP by point (all-gather of the
     deltas, reduce-scatter of dL/d delta), render their views, all-reduce the MLP-gradient bucket.  Every MLP parameter's
@@ -243,7 +246,11 @@ def test_point_sharded_deformation_equals_the_single_process_step(tmp_path, worl
     ref_params = {k: p.grad for k, p in field.named_parameters()}
     got = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
     covered = torch.zeros(T, P)
+    views_done = torch.zeros(T, V)
     for r, g in enumerate(got):
+        assert g["world_size_seen"] == world and g["group_size"] == max(1, world // T)
+        for t in g["timesteps"]:
+            views_done[t, g["views"]] += 1
         for k, ref in ref_params.items():
             scale = ref.abs().max().item()
             assert scale > 0, f"{k}: the reference gradient is all zero -- the test would prove nothing"
@@ -254,6 +261,7 @@ def test_point_sharded_deformation_equals_the_single_process_step(tmp_path, worl
             assert g["desc"]["mlp_points_per_rank"] == g["hi"] - g["lo"] < P
             assert g["desc"]["all_gather_bytes_per_timestep"] == 28 * P
     assert torch.equal(covered, torch.ones(T, P)), "every (timestep, point) must be evaluated by exactly one rank"
+    assert torch.equal(views_done, torch.ones(T, V)), "every (timestep, view) must be rendered by exactly one rank"
     # point_latent: summed over the timesteps in the single-process step; a rank's local leaf holds its timesteps' share of
     # its rows, so the ranks' contributions add up to the reference row by row
     total = torch.zeros_like(lat.grad)
@@ -305,7 +313,7 @@ def test_bench_self_launches_two_ranks_on_one_device():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("cfg,ranks", [("c4", 1), ("c4", 2), ("c5", 2)])
+@pytest.mark.parametrize("cfg,ranks", [("c4", 1), ("c4", 2), ("c5", 2), ("c4", 8), ("c5", 8)])
 def test_bench_dynamic_configs_share_the_step_between_ranks(cfg, ranks):
     """BASELINE configs[3] / [4] as `bench.py --config c4 | c5` runs them (at a reduced Gaussian count, the shapes and the
     control flow are the real ones): the step's (timestep, view) renders are SHARED by the ranks (strong scaling), every
@@ -327,6 +335,13 @@ def test_bench_dynamic_configs_share_the_step_between_ranks(cfg, ranks):
         from manigaussian_amd.deform import DeformationField
         n_params = sum(p.numel() for p in DeformationField().parameters())
         assert j["distributed"]["allreduce_bytes_per_step"] == 4 * n_params  # the MLP's gradients, nothing else
+        assert j["distributed"]["world_size_seen"] == ranks and len(j["distributed"]["device_ids"]) == ranks
+        part = c["partition"]
+        # the driver's 8-GPU shapes: configs[3] = 4 timesteps x 4 views (2 ranks share a timestep, 2 views each),
+        # configs[4] = 1 timestep x 8 views (all 8 ranks share it, one view each, 6000 / 8 = 750 points of its MLP each)
+        T_total = {"c4": 4, "c5": 1}[cfg]
+        assert part["ranks_sharing_a_timestep"] == max(1, ranks // T_total)
+        assert part["mlp_points_per_rank"] == -(-6000 // max(1, ranks // T_total))
 
 
 @pytest.mark.gpu
