@@ -33,6 +33,16 @@ __device__ __forceinline__ uint32_t div_up_u(uint32_t a, uint32_t b) { return (a
 // tmp: LDS scratch of >= 128 entries.  blockDim.x <= 1024 (16 waves).
 __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t* total) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = (nt + 63) >> 6;
+  if (n <= 64) {  // (workgroup-uniform) one wave, one DPP scan, one barrier: the 64 tiles of a 128 x 128 image
+    if (wv == 0) {
+      const uint32_t x = lane < n ? v[lane] : 0u;
+      const uint32_t incl = wave_incl_scan_add_u32(x);
+      if (lane < n) v[lane] = incl - x;
+      if (lane == 63) *total = incl;
+    }
+    __syncthreads();
+    return;
+  }
   const int per = (n + nt - 1) / nt;
   const int b = tid * per, e = min(n, b + per);
   uint32_t sum = 0;
@@ -137,6 +147,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   block_exclusive_scan(s_start, S, tmp, &total);
   if (tables) {
     for (int t = tid; t < T; t += blockDim.x) ranges[t] = make_uint2(s_start[t], s_start[t] + tile_hist[t]);
+    if (seg == 0u) return;  // the bucket rank reads the ranges only: no segment table
     for (int t = tid; t < S; t += blockDim.x) s_base[t] = div_up_u(tile_hist[t], seg);
     __syncthreads();
     block_exclusive_scan(s_base, S, tmp, &total);
@@ -983,17 +994,16 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
   if (which == 0) {
     // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
-                       tiles_x, nblk, (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, im.ref_count, g.rect, g.depths,
+                       tiles_x, nblk, bucket ? 0u : (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, im.ref_count, g.rect, g.depths,
                        im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready, im.nonce);
     return hipGetLastError();
   }
   if (bucket) {  // which == 1: the bucket rank does the work of segment sort + rank merge; which == 2: nothing left to do
     if (which == 1) {
-      // parts per tile: enough workgroups to fill the chip (two of them fit a CU), a power of two <= 8.  (seg, which this
-      // binning has no use for, overrides it for experiments: 512 -> 1, 1024 -> 2, 4096 -> 8.)
+      // parts per tile: enough workgroups to give every CU one (two fit a CU), a power of two <= 8: 4 at the 64 tiles of a
+      // 128 x 128 image (measured: 8 parts -- two workgroups per CU -- gain nothing, the phases are issue-bound per CU)
       int split = 1;
       while (split < 8 && T * split * 2 <= 256) split *= 2;
-      if (seg == 512) split = 1; else if (seg == 1024) split = 2; else if (seg == 4096) split = 8;
       const int grid = ((T + 7) / 8) * 8 * split;
       hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(grid), dim3(BK_THREADS), 0, s, T, split, dbg & 256, im.ranges, b.keys_unsorted,
                          b.point_list, im.ready ? im.ready + 1 : nullptr);

@@ -89,6 +89,10 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   __shared__ uint2 gid[NW][32];           // per wave: {instance id, Gaussian} of the group's lanes (0xffffffff: empty lane)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: scalar chunk loops and addresses
+  // Chunks of a block by wave: wave w walks chunks cw, cw + NW, ...  Waves w, w + 4, w + 8 share a SIMD, and a block's FRONT
+  // chunks are its long ones (every pixel alive): chunks 4 .. 7 go to waves 7 .. 4, so that the SIMD that holds chunk 0 holds
+  // chunk 7 (not 4) beside it, the one with chunk 3 holds chunk 4 (experiment, MgsOptions.dbg & 2048: the identity)
+  const int cw = ((r.dbg & 2048) == 0 && (w & 4) && NW >= 8) ? (w ^ 3) : w;
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;
@@ -146,8 +150,8 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   if (lcmax > NWF) __syncthreads();  // (workgroup-uniform) only blocks with a second round read the table
   // ---- this wave's FIRST chunk (c = w): its per-pixel state and its survivors' records are requested now, so that they
   //      arrive while q is being computed (they used to be three more round trips after the barrier) ----
-  const bool pf = (uint32_t)w < lcmax;
-  const uint32_t c1 = (uint32_t)w;            // my first chunk
+  const bool pf = (uint32_t)cw < lcmax;
+  const uint32_t c1 = (uint32_t)cw;           // my first chunk
   uint32_t pf_last = 0u, pf_id = 0u;
   float pf_Tin = 1.0f, pf_Tmid = 1.0f;
   float4 pf_g0 = make_float4(0, 0, 0, 0), pf_g1 = make_float4(0, 0, -1.f, -1.f);
@@ -222,13 +226,13 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
     if (fastB) {
       // my chunks from the last one down to the first, one running sum (back to front, chunk order)
       uint32_t hi = lcmax;  // the sum holds q[hi .. lcmax)
-      for (uint32_t c = (uint32_t)w + ((lcmax - 1u - (uint32_t)w) / (uint32_t)NW) * (uint32_t)NW;; c -= (uint32_t)NW) {
+      for (uint32_t c = (uint32_t)cw + ((lcmax - 1u - (uint32_t)cw) / (uint32_t)NW) * (uint32_t)NW;; c -= (uint32_t)NW) {
         for (uint32_t c2 = hi; c2-- > c + 1u;) {
           const float v = qs[c2 * 64 + (uint32_t)lane];
           pf_B += (c2 < lc) ? v : 0.f;
         }
         hi = c + 1u;
-        if (c == (uint32_t)w) break;
+        if (c == (uint32_t)cw) break;
         q[slot_of(c) * 64 + lane] = pf_B;
       }
     } else {
@@ -253,9 +257,9 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   const int n_ = lane & 31, h_ = lane >> 5;
   const float bx0 = p.bxmin, by0 = p.bymin;  // block origin (pixel coordinates are bx0 + (p&7), by0 + (p>>3))
 
-  for (uint32_t c = (uint32_t)w; c < lcmax; c += NW) {
+  for (uint32_t c = (uint32_t)cw; c < lcmax; c += NW) {
     // ---- pixel-lane: state of this chunk for my pixel ----
-    const bool first_it = c == (uint32_t)w;  // staged by the prologue
+    const bool first_it = c == (uint32_t)cw;  // staged by the prologue
     const size_t slot = slot_of(c);
     if (first_it) wave_lds_sync();
     const uint32_t last = first_it ? __float_as_uint(pd[w][lane].z) : ((c < lc) ? last_pos[slot * 64 + lane] : 0u);

@@ -1,4 +1,4 @@
-"""Phase timeline of the bucket-rank binning kernel (diagnostic): python scripts/trace_bin.py [P] [W] [seg]"""
+"""Phase timeline of the bucket-rank binning kernel (diagnostic): python scripts/trace_bin.py [P] [W]"""
 import os
 import sys
 
@@ -13,8 +13,6 @@ dev = torch.device("cuda:0")
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 F = 32
-if len(sys.argv) > 3:
-    _lib.set_option("seg", int(sys.argv[3]))
 sc = {k: v.to(dev) for k, v in syn.make_scene(P, F=F, M=4, seed=0).items()}
 cam = syn.circle_cameras(8, W, W, negative_focal=True)[0]
 rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))

@@ -11,7 +11,9 @@ from manigaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, 
 from manigaussian_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
-P, F, W = 100000, 32, 128
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+W = 128
 sc = {k: v.to(dev) for k, v in syn.make_scene(P, F=F, M=4, seed=0).items()}
 cam = syn.circle_cameras(8, W, W, negative_focal=True)[0]
 rast = GaussianRasterizer(GaussianRasterizationSettings(**syn.camera_settings_kwargs(cam, 1, True, device=dev)))
