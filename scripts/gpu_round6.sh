@@ -9,7 +9,7 @@
 #   configs    bench lines of c2, c5shape, ref16k, views 4/8, c4, c5
 #   stats      rocprofv3 --kernel-trace --stats of the default bench (graph and eager-st)
 #   pmc        the six counter passes (one group per pass) -> sq_counters.json
-#   trace      s_memtime timelines of the render kernels
+#   trace      s_memtime timelines of the render kernels and of the bucket-rank binning
 #   extra      $EXTRA_CMD (a shell command), output -> $OUT/extra.log
 TAG=${1:-run}; shift
 OUT=gpurun_out/$TAG
@@ -84,7 +84,8 @@ for W in golden quick tests host pmc bench configs stats trace extra; do
     done ;;
   trace)
     timeout 200 python scripts/trace_fwd.py > $OUT/trace_fwd.log 2>&1; echo "trace rc=$?"; tail -22 $OUT/trace_fwd.log
-    timeout 200 python scripts/trace_bwd.py > $OUT/trace_bwd.log 2>&1; echo "trace bwd rc=$?"; tail -22 $OUT/trace_bwd.log ;;
+    timeout 200 python scripts/trace_bwd.py > $OUT/trace_bwd.log 2>&1; echo "trace bwd rc=$?"; tail -22 $OUT/trace_bwd.log
+    (timeout 200 python scripts/trace_bin.py; timeout 200 python scripts/trace_bin.py 16384 128) > $OUT/trace_bin.log 2>&1; echo "trace bin rc=$?"; tail -34 $OUT/trace_bin.log ;;
   extra)
     timeout ${EXTRA_TIMEOUT:-600} bash -c "$EXTRA_CMD" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -40 $OUT/extra.log ;;
   esac
