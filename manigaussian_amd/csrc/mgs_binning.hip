@@ -607,7 +607,11 @@ __device__ __forceinline__ BkMap bk_map(uint64_t kmin, uint64_t kmax) {
   m.tmax = (uint32_t)(r >> m.shift);
   return m;
 }
-__device__ __forceinline__ uint32_t bk_t(const BkMap& m, uint64_t key) { return (uint32_t)((key - m.kmin) >> m.shift); }  // < 2^24
+__device__ __forceinline__ uint32_t bk_t(const BkMap& m, uint64_t key) {  // < 2^24
+  const uint64_t d = key - m.kmin;
+  // (one v_alignbit_b32 or one 32-bit shift -- m.shift is wave-uniform -- instead of a 64-bit shift)
+  return m.shift < 32u ? __builtin_amdgcn_alignbit((uint32_t)(d >> 32), (uint32_t)d, m.shift) : ((uint32_t)(d >> 32) >> (m.shift - 32u));
+}
 // bucket of t inside the interval [t0, ...] at `scale` buckets per unit, clamped to [0, nb): monotone in t whatever the bounds
 __device__ __forceinline__ uint32_t bk_bucket(uint32_t t, uint32_t t0, float scale, uint32_t nb) {
   const uint32_t d = t > t0 ? t - t0 : 0u;
@@ -762,7 +766,9 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
       for (int j = 0; j < 4; j++) S.c1[4 * lane + j] = e[j];
       if (lane == 0) S.c1[BK_NB1] = L;
       // this part: [first bucket that starts at or behind q L / split, first bucket at or behind (q + 1) L / split)
-      const uint32_t xlo = (uint32_t)(((uint64_t)q * L) / (uint32_t)split), xhi = (uint32_t)(((uint64_t)(q + 1u) * L) / (uint32_t)split);
+      // (split is a power of two: shifts, not the 64-bit software division two quotients would cost this one wave)
+      const int lsplit = 31 - __builtin_clz((uint32_t)split);
+      const uint32_t xlo = (uint32_t)(((uint64_t)q * L) >> lsplit), xhi = (uint32_t)(((uint64_t)(q + 1u) * L) >> lsplit);
       uint32_t cl = BK_NB1, ch = BK_NB1;
 #pragma unroll
       for (int j = 3; j >= 0; j--) {
