@@ -197,6 +197,7 @@ def get_option(key: str) -> int:
 
 
 LONG_LIST = 8192  # instances per tile above which 4096-key segments pay (each key is ranked in half as many segments)
+VERY_LONG_LIST = 24576  # ... above which the segment sort + rank merge beats the bucket rank (scripts/diag/quick_binmode.py)
 
 
 def auto_seg(a, opts, mark_R, tiles):
@@ -206,6 +207,13 @@ def auto_seg(a, opts, mark_R, tiles):
     left alone."""
     if opts["seg"] == 2048 and mark_R and mark_R > LONG_LIST * tiles:
         a.opt.seg = 4096
+    # ... and the bucket rank (bin_mode 2: a tile's slice in registers, <= 16 384 keys) hands VERY long lists -- more than 24 576
+    # instances per tile on average, e.g. 2 000 000 Gaussians on a 128 x 128 image -- to the segment sort + rank merge, whose
+    # work is spread over one workgroup per segment (590 against 505 us there; the bucket rank wins at every BASELINE shape)
+    if opts["bin_mode"] == 2 and mark_R and mark_R > VERY_LONG_LIST * tiles:
+        a.opt.bin_mode = 1
+        if opts["seg"] == 2048:
+            a.opt.seg = 4096
 
 
 def fill_options(a, opts=None):

@@ -1006,10 +1006,12 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
   }
   if (bucket) {  // which == 1: the bucket rank does the work of segment sort + rank merge; which == 2: nothing left to do
     if (which == 1) {
-      // parts per tile: enough workgroups to give every CU one (two fit a CU), a power of two <= 8: 4 at the 64 tiles of a
-      // 128 x 128 image (measured: 8 parts -- two workgroups per CU -- gain nothing, the phases are issue-bound per CU)
+      // parts per tile: a power of two <= 4 that keeps the grid at or below two workgroups per CU -- 4 at the 64 tiles of a
+      // 128 x 128 image, 2 at 256 tiles, 1 from 512 tiles on (measured, scripts/diag/quick_split.py: 128 x 128 15.1 us with 4
+      // parts against 23.8 / 20.3 / 25.1 with 1 / 2 / 8; 256 x 256 99.9 with 2 against 104.8 / 113.9 with 1 / 4)
       int split = 1;
-      while (split < 8 && T * split * 2 <= 256) split *= 2;
+      while (split < 4 && T * split * 2 <= 512) split *= 2;
+      if (dbg & 0x7000) split = 1 << (((dbg >> 12) & 7) - 1);  // (experiments: MgsOptions.dbg bits 12-14 = 1 + log2 of the parts)
       const int grid = ((T + 7) / 8) * 8 * split;
       hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(grid), dim3(BK_THREADS), 0, s, T, split, dbg & 256, im.ranges, b.keys_unsorted,
                          b.point_list, im.ready ? im.ready + 1 : nullptr);

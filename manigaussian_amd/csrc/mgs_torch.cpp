@@ -704,6 +704,10 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
   a.async_forward = lazy ? 1 : 0;
   a.opt = opt;
   if (opt.seg == 2048 && mark_R > 8192 * T) a.opt.seg = 4096;  // long per-tile lists (manigaussian_amd/_lib.py auto_seg)
+  if (opt.bin_mode == 2 && mark_R > 24576 * T) {               // very long ones: segment sort + rank merge (same place)
+    a.opt.bin_mode = 1;
+    if (opt.seg == 2048) a.opt.seg = 4096;
+  }
   if (want_grad) {
     a.bwd_accum = grad_buffer.data_ptr();
     a.bwd_accum_bytes = GL.accum_bytes;
