@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32
 }
 
 // ================================ bucket rank (round 6): ONE launch instead of segment sort + rank merge ==================
-// `split` workgroups of 1024 threads per tile (the host picks split so that the grid fills the chip: 4 at 64 tiles); the
+// `split` workgroups of 1024 threads per tile (the host picks split so that every CU gets one: 4 at 64 tiles); the
 // tile's keys never leave the CU between "unsorted slice" and "sorted ids".  Every workgroup of a tile
 //   A. takes the tile's slice into REGISTERS (<= 16 keys per thread; longer slices are re-streamed from L2 instead) and finds
 //      BOUNDS of its keys: min / max of the depth words (32-bit DPP reductions; the index words only if all depths are equal);
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32
 //      (depth bits << 32 | id) -- so is floor(t * scale) for any scale > 0, with or without clamping: every key of bucket b
 //      precedes every key of bucket b + 1.  LEVEL 1: 256 such buckets, histogram in LDS, scanned by one wave, which also
 //      cuts THIS workgroup's share out of the sorted order -- the consecutive buckets holding keys [q L / split,
-//      (q + 1) L / split), cut at bucket boundaries -- into rounds of consecutive buckets holding <= 4096 keys;
+//      (q + 1) L / split), cut at bucket boundaries -- into rounds of consecutive buckets holding <= 8192 keys;
 //   C. per round, LEVEL 2: the round's keys (still in their registers) onto <= 1024 fine buckets (about four keys each; the
 //      level-1 table serves as the keys' CDF, so the fine buckets follow the depth density): count, scan, a returning LDS atomic on the bucket's start hands out its slots (keys
 //      grouped by bucket in LDS); then every BUCKET's owner thread reads its keys once, ranks them in registers (keys
@@ -576,15 +576,16 @@ __global__ void __launch_bounds__(SEGN / KPT) bin_merge_emit_kernel(const uint32
 // Rounds 2-5 ran 66 dependent compare-exchange stages + a rank merge.
 // Depth distributions that defeat the buckets are bounded, never wrong: a fine bucket of 5 .. 8 keys is ranked in registers
 // too, 9 .. 64 by a wave (one lane per key); more than that (hundreds of equal depths among spread-out ones) and the round takes
-// a bitonic network over the same LDS array; a level-1 bucket that alone exceeds a round (more than 4096 keys of one tile
+// a bitonic network over the same LDS array; a level-1 bucket that alone exceeds a round (more than 8192 keys of one tile
 // within 1/256 of its key range) is ranked against the streamed slice directly -- slow, correct.
 constexpr int BK_THREADS = 1024;
 constexpr int BK_KPT = 16;                       // keys a thread keeps in registers
 constexpr int BK_INREG = BK_THREADS * BK_KPT;    // longest slice held in registers
 constexpr int BK_NB1 = 256;                      // level-1 buckets (four per lane of the wave that scans them)
-constexpr int BK_CAP2 = 4096;                    // keys per round
+constexpr int BK_CAP2 = 8192;                    // keys per round (a 1 024-thread workgroup at ~126 registers fills a CU by itself:
+                                                 // the LDS a second one would need is free)
 constexpr int BK_SMALL = 1024;                   // slices up to this length skip level 1 (uniform fine buckets: no CDF)
-constexpr int BK_NB2 = 1024;                     // level-2 buckets (four keys each on average: one owner thread per bucket)
+constexpr int BK_NB2 = 2048;                     // level-2 buckets (four keys each on average: one or two buckets per owner thread)
 constexpr uint32_t BK_LOOP_MAX = 64;             // largest fine bucket ranked by comparisons (one lane of a wave per key)
 constexpr int BK_BIG_LIST = 512;                 // fine buckets of 9 .. 64 keys handed to waves per round
 
@@ -620,6 +621,22 @@ __device__ __forceinline__ uint32_t bk_bucket(uint32_t t, uint32_t t0, float sca
 }
 __device__ __forceinline__ uint32_t wave_umin(uint32_t v) { return ~wave_umax(~v); }
 
+// A slice longer than the registers hold is streamed from L2 -- eight keys per thread in flight (a plain loop waits out one
+// load latency per key).  f(key) is called for every key of the slice.
+#define BK_STREAM(src, L, tid, kbuf, BODY)                                               \
+  for (uint32_t e0_ = 0; e0_ < (L); e0_ += 8u * BK_THREADS) {                             \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; u_++) {                                    \
+      const uint32_t e_ = e0_ + (uint32_t)u_ * BK_THREADS + (uint32_t)(tid);              \
+      kbuf[4 + u_] = e_ < (L) ? (src)[e_] : ~0ull;                                        \
+    }                                                                                     \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; u_++) {                                    \
+      const uint32_t e_ = e0_ + (uint32_t)u_ * BK_THREADS + (uint32_t)(tid);              \
+      const bool in_ = e_ < (L);                                                          \
+      const uint64_t key_ = kbuf[4 + u_];                                                 \
+      BODY                                                                                \
+    }                                                                                     \
+  }
+
 struct BkShared {
   uint64_t sk[BK_CAP2 + 8];       // the round's keys grouped by level-2 bucket (+ 8: an owner reads 8 slots from its start)
   uint32_t sid[BK_CAP2];          // ... their ids in order
@@ -631,11 +648,14 @@ struct BkShared {
   uint32_t hmin, hmax, lmin, lmax, nrounds, big, gath, nbig;
 };
 
-// Exclusive scan of cnt[0 .. nb) in place (nb a power of two, 256 .. 1024: one count per thread), two barriers; *big is set if
-// a count exceeds BK_LOOP_MAX.  All 1024 threads call it.
+// Exclusive scan of cnt[0 .. nb) in place (nb a power of two, 256 .. 2048: one or two counts per thread), two barriers; *big is
+// set if a count exceeds BK_LOOP_MAX.  All 1024 threads call it.
 __device__ __forceinline__ void bk_scan(BkShared& S, uint32_t nb, int tid, int lane, int wv) {
-  const uint32_t c = (uint32_t)tid < nb ? S.cnt[tid] : 0u;
-  if (c > BK_LOOP_MAX) S.big = 1u;  // (same value from everybody who writes)
+  const bool two = nb > (uint32_t)BK_THREADS;  // (workgroup-uniform) 2 048 buckets: two consecutive counts per thread
+  const uint32_t i0 = two ? 2u * (uint32_t)tid : (uint32_t)tid;
+  const uint32_t c0 = i0 < nb ? S.cnt[i0] : 0u, c1 = two ? S.cnt[i0 + 1u] : 0u;
+  if (c0 > BK_LOOP_MAX || c1 > BK_LOOP_MAX) S.big = 1u;  // (same value from everybody who writes)
+  const uint32_t c = c0 + c1;
   const uint32_t incl = wave_incl_scan_add_u32(c);
   if (lane == 63) S.tmp[wv] = incl;
   __syncthreads();
@@ -643,7 +663,8 @@ __device__ __forceinline__ void bk_scan(BkShared& S, uint32_t nb, int tid, int l
   const uint32_t wt = lane < 16 ? S.tmp[lane] : 0u;
   const uint32_t wi = wave_incl_scan_add_u32(wt);
   const uint32_t wave_off = bcast_lane_u32(wi - wt, wv);
-  if ((uint32_t)tid < nb) S.cnt[tid] = wave_off + incl - c;
+  if (i0 < nb) S.cnt[i0] = wave_off + incl - c;
+  if (two) S.cnt[i0 + 1u] = wave_off + incl - c + c0;
   __syncthreads();
 }
 
@@ -710,7 +731,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
   // ---- A. bounds of the keys
   if (tid == 0) { S.hmin = ~0u; S.hmax = 0u; S.lmin = ~0u; S.lmax = 0u; S.nrounds = 0u; S.big = 0u; S.nbig = 0u; }
   if (tid <= BK_NB1) S.c1[tid] = 0u;
-  S.cnt[tid] = 0u;
+  S.cnt[tid] = 0u; S.cnt[tid + BK_THREADS] = 0u;
   if (tid == 0) S.cnt[BK_NB2] = 0u;
   uint32_t hlo = ~0u, hhi = 0u;
   if (inreg) {
@@ -718,7 +739,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     for (int i = 0; i < BK_KPT; i++)
       if (i < kpt && ((have >> i) & 1u)) { const uint32_t h = (uint32_t)(k[i] >> 32); hlo = min(hlo, h); hhi = max(hhi, h); }
   } else {
-    for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint32_t h = (uint32_t)(src[e] >> 32); hlo = min(hlo, h); hhi = max(hhi, h); }
+    BK_STREAM(src, L, tid, k, { if (in_) { const uint32_t h = (uint32_t)(key_ >> 32); hlo = min(hlo, h); hhi = max(hhi, h); } })
   }
   MGS_BKTRACE(2);
   __syncthreads();
@@ -733,7 +754,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
       for (int i = 0; i < BK_KPT; i++)
         if (i < kpt && ((have >> i) & 1u)) { llo = min(llo, (uint32_t)k[i]); lhi = max(lhi, (uint32_t)k[i]); }
     } else {
-      for (uint32_t e = tid; e < L; e += BK_THREADS) { const uint32_t v = (uint32_t)src[e]; llo = min(llo, v); lhi = max(lhi, v); }
+      BK_STREAM(src, L, tid, k, { if (in_) { llo = min(llo, (uint32_t)key_); lhi = max(lhi, (uint32_t)key_); } })
     }
     llo = wave_umin(llo); lhi = wave_umax(lhi);
     if (lane == 0) { atomicMin(&S.lmin, llo); atomicMax(&S.lmax, lhi); }
@@ -751,7 +772,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
       for (int i = 0; i < BK_KPT; i++)
         if (i < kpt && ((have >> i) & 1u)) atomicAdd(&S.c1[bk_bucket(bk_t(m, k[i]), 0u, scale1, BK_NB1)], 1u);
     } else {
-      for (uint32_t e = tid; e < L; e += BK_THREADS) atomicAdd(&S.c1[bk_bucket(bk_t(m, src[e]), 0u, scale1, BK_NB1)], 1u);
+      BK_STREAM(src, L, tid, k, { if (in_) atomicAdd(&S.c1[bk_bucket(bk_t(m, key_), 0u, scale1, BK_NB1)], 1u); })
     }
     __syncthreads();
     MGS_BKTRACE(4);
@@ -809,7 +830,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     const uint32_t n = small ? L : S.c1[r1] - first;
     if (rd > 0u) {  // (the first round's tables were zeroed in the prologue)
       __syncthreads();
-      S.cnt[tid] = 0u;
+      S.cnt[tid] = 0u; S.cnt[tid + BK_THREADS] = 0u;
       if (tid == 0) { S.cnt[BK_NB2] = 0u; S.big = 0u; S.nbig = 0u; }
       __syncthreads();
     }
@@ -836,23 +857,29 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     // Four keys per fine bucket on average: ONE owner thread per bucket ranks its <= 8 keys in registers in one batch (a
     // bucket per key costs four dependent passes per thread).
     uint32_t nb = 256;
-    while (4u * nb < n) nb <<= 1;   // n / 4 <= nb < n / 2 (or 256): 256 .. 1024
+    while (4u * nb < n) nb <<= 1;   // n / 4 <= nb < n / 2 (or 256): 256 .. 2048
     const float scale2 = (float)nb / ((float)m.tmax + 1.0f);
-    // a slice that is not in registers is streamed and the round's keys take the first four register slots in arrival order
+    // a slice that is not in registers is streamed and the round's keys take the first eight register slots in arrival order
     uint32_t inr = have;
     if (!inreg) {
       inr = 0u;
       if (tid == 0) S.gath = 0u;
       __syncthreads();
-      for (uint32_t e0 = 0; e0 < L; e0 += BK_THREADS) {
-        const uint32_t e = e0 + (uint32_t)tid;
-        const uint64_t v = e < L ? src[e] : ~0ull;
-        const uint32_t b = e < L ? bk_bucket(bk_t(m, v), 0u, scale1, BK_NB1) : 0xffffffffu;
-        if (b >= r0 && b < r1) S.sk[atomicAdd(&S.gath, 1u)] = v;
-      }
+      // (one LDS atomic per wave and batch element, not per key: 1 024 same-address atomics serialise)
+      BK_STREAM(src, L, tid, k, {
+        const uint32_t b_ = in_ ? bk_bucket(bk_t(m, key_), 0u, scale1, BK_NB1) : 0xffffffffu;
+        const bool take_ = b_ >= r0 && b_ < r1;
+        const unsigned long long mk_ = ballot(take_);
+        if (mk_ != 0ull) {
+          uint32_t base_ = 0u;
+          if (lane == 0) base_ = atomicAdd(&S.gath, (uint32_t)__builtin_popcountll(mk_));
+          base_ = bcast_lane_u32(base_, 0);
+          if (take_) S.sk[base_ + (uint32_t)__builtin_popcountll(mk_ & ((1ull << lane) - 1ull))] = key_;
+        }
+      })
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < 8; i++) {  // (n <= 8 192: eight slots; the streaming buffer, slots 4 .. 11, is free again)
         const uint32_t e = (uint32_t)tid + 1024u * i;
         k[i] = ~0ull;
         if (e < n) { k[i] = S.sk[e]; inr |= 1u << i; }
@@ -905,8 +932,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     if (rd == 0u) MGS_BKTRACE(10);
     if (!skewed) {
       // every bucket's owner ranks its keys (each key is read once)
-      if ((uint32_t)tid < nb) {  // (whole waves: nb is a multiple of 64)
-        const uint32_t b = (uint32_t)tid;
+      for (uint32_t b = (uint32_t)tid; b < nb; b += BK_THREADS) {  // (whole waves: nb is a multiple of 64)
         const uint32_t b0 = b ? S.cnt[b - 1u] : 0u, c = S.cnt[b] - b0;
         if (ballot(c > 4u) == 0ull) {
           bk_owner_sort<4>(S, b0, c);
@@ -1006,11 +1032,12 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
   }
   if (bucket) {  // which == 1: the bucket rank does the work of segment sort + rank merge; which == 2: nothing left to do
     if (which == 1) {
-      // parts per tile: a power of two <= 4 that keeps the grid at or below two workgroups per CU -- 4 at the 64 tiles of a
-      // 128 x 128 image, 2 at 256 tiles, 1 from 512 tiles on (measured, scripts/diag/quick_split.py: 128 x 128 15.1 us with 4
-      // parts against 23.8 / 20.3 / 25.1 with 1 / 2 / 8; 256 x 256 99.9 with 2 against 104.8 / 113.9 with 1 / 4)
+      // parts per tile: a power of two <= 4 that keeps the grid at ONE workgroup per CU (1 024 threads at ~126 registers fill a
+      // CU's register file: a second workgroup waits for the first) -- 4 at the 64 tiles of a 128 x 128 image, 1 from 256 tiles
+      // on (measured, scripts/diag/quick_split.py: 128 x 128 15.1 us with 4 parts against 18.9 / 16.6 / 25.1 with 1 / 2 / 8;
+      // 500 000 Gaussians at 256 x 256 69.3 with 1 against 81.1 / 85.3 with 2 / 4)
       int split = 1;
-      while (split < 4 && T * split * 2 <= 512) split *= 2;
+      while (split < 4 && T * split * 2 <= 256) split *= 2;
       if (dbg & 0x7000) split = 1 << (((dbg >> 12) & 7) - 1);  // (experiments: MgsOptions.dbg bits 12-14 = 1 + log2 of the parts)
       const int grid = ((T + 7) / 8) * 8 * split;
       hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(grid), dim3(BK_THREADS), 0, s, T, split, dbg & 256, im.ranges, b.keys_unsorted,
