@@ -389,8 +389,8 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   const int tiles_x = (a->W + TILE - 1) / TILE, tiles_y = (a->H + TILE - 1) / TILE;
   (void)radii;
   for (int k = 0; k < 3; k++) {
-    StageTimer t(ST_BIN_SCATTER + k, stream);
     if (k == 2 && bucket_rank(o, T)) break;  // (the bucket rank of stage 1 wrote the sorted ids)
+    StageTimer t(ST_BIN_SCATTER + k, stream);
     MGS_STAGE(launch_bin_segsort(k, lds, bucket_rank(o, T), g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, o.dbg, status, stream),
               "binning", a->debug, stream);
   }
@@ -777,8 +777,8 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
   const StatusSink status = {host_status, a->status_tag};
   for (int k = 0; k < 3; k++) {
-    StageTimer t(ST_BIN_SCATTER + k, stream);
     if (k == 2 && bucket_rank(o, at.T)) break;
+    StageTimer t(ST_BIN_SCATTER + k, stream);
     MGS_HIP(launch_bin_segsort(k, lds, bucket_rank(o, at.T), g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, o.dbg, status, stream),
             "binning (views)");
   }
