@@ -82,6 +82,18 @@ CASES = {
     "long_cluster_20000_among_5000_streamed_rank": dict(P=25000, W=16, same=20000),
     "baseline_shape_100k_128": dict(P=100000, W=128),
     "manigaussian_shape_16384_128": dict(P=16384, W=128),
+    # the kernel's size classes, one tile each, either side of every boundary: one key; <= 1 024 keys skip level 1; a round holds
+    # 8 192; 16 384 keys fit the registers
+    "one_gaussian": dict(P=1, W=16, exact=True),
+    "seven_gaussians": dict(P=7, W=16, exact=True),
+    "slice_1024_no_level_1": dict(P=1024, W=16, exact=True),
+    "slice_1025_level_1": dict(P=1025, W=16, exact=True),
+    "slice_8192_one_round": dict(P=8192, W=16, exact=True),
+    "slice_8193_two_rounds": dict(P=8193, W=16, exact=True),
+    "slice_16384_in_registers": dict(P=16384, W=16, exact=True),
+    "slice_16385_streamed": dict(P=16385, W=16, exact=True),
+    "ragged_tiles_80x48_30000": dict(P=30000, W=80, H=48),
+    "many_tiles_256x256_200000": dict(P=200000, W=256),
 }
 
 
@@ -92,9 +104,14 @@ def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mo
     if bin_mode == 1 and case["P"] > 20000 and case["W"] == 16:
         pytest.skip("the segment sort's one-tile long lists are covered by test_gpu_parity (seg 4096)")
     dev = torch.device("cuda:0")
-    P, W = case["P"], case["W"]
+    P, W, H = case["P"], case["W"], case.get("H", case["W"])
     d = _scene(P, 11, dev)
-    cam = syn.circle_cameras(4, W, W, negative_focal=True)[1]
+    cam = syn.circle_cameras(4, W, H, negative_focal=True)[1]
+    if case.get("exact"):
+        # every Gaussian in front of the camera, small: the one tile's slice holds exactly P keys (tight_bins 0)
+        _plane(d, cam, torch.arange(P, device=dev), 1.5, 0.01)
+        d["means3D"] += 0.2 * torch.linspace(-1, 1, max(P, 2), device=dev)[:P, None] * torch.linalg.inv(cam["world_view_transform"].to(dev).T)[:3, 2]
+        d["scales"][:] = 0.004
     if case.get("same"):
         # duplicated positions in front of the camera: bit-equal depths, bit-equal screen positions
         wv = cam["world_view_transform"].to(dev)
@@ -108,9 +125,11 @@ def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mo
         _lib.set_option("bin_mode", bin_mode)
         for tight in (0, 1):
             _lib.set_option("tight_bins", tight)
-            ranges, keys, plist, R_ref, color = _lists(d, cam, W, W, 3)
+            ranges, keys, plist, R_ref, color = _lists(d, cam, W, H, 3)
             n = _check_order(ranges, keys, plist)
             assert n > 0 and torch.isfinite(color).all()
+            if case.get("exact") and tight == 0:
+                assert n == P, f"the one tile's slice should hold exactly {P} keys, holds {n}"
             if tight == 0:
                 assert n == R_ref, "tight_bins = 0 bins exactly the reference's 3-sigma-rect instances"
             else:
