@@ -5,6 +5,7 @@ caller takes, its results are those of the ctypes shim (same kernels: images bit
 its waiting / retry / overflow protocol, autograd corner cases."""
 import gc
 import os
+import time
 import warnings
 
 import pytest
@@ -321,6 +322,7 @@ def test_two_python_threads_render_on_one_device_while_a_third_reads_the_status(
             while not done.is_set():
                 mg.check_status(dev, wait=(i % 2 == 0))
                 i += 1
+                time.sleep(2e-4)  # (a reader that spins takes the GIL from the renderers: the test then lasts minutes)
         except Exception as ex:  # noqa: BLE001
             errors.append(ex)
 
