@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   // Chunks of a block by wave: wave w walks chunks cw, cw + NW, ...  Waves w, w + 4, w + 8 share a SIMD, and a block's FRONT
   // chunks are its long ones (every pixel alive): chunks 4 .. 7 go to waves 7 .. 4, so that the SIMD that holds chunk 0 holds
   // chunk 7 (not 4) beside it, the one with chunk 3 holds chunk 4 (experiment, MgsOptions.dbg & 2048: the identity)
-  const int cw = ((r.dbg & 2048) == 0 && (w & 4) && NW >= 8) ? (w ^ 3) : w;
+  int cw = ((r.dbg & 2048) == 0 && (w & 4) && NW >= 8) ? (w ^ 3) : w;
   int tile, sub;
   map_block(blockIdx.x, tile, sub);
   if (tile >= r.tiles_x * r.tiles_y) return;
@@ -126,6 +126,20 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
   const uint32_t lcmax = wave_umax(lc);
   if (lcmax == 0) return;
   const bool any = lc > 0;  // this pixel visited at least one chunk (=> inside)
+  // Round 6: a block of 9 or 10 chunks -- the blocks this kernel's duration is made of (profiles/r06_trace_bwd.log: the THIRD wave
+  // of a SIMD is served last and finishes ~20 k cycles after the other two) -- cuts its extra chunks 8, 9 in two: waves 8 + 9 take
+  // the pixel tiles u = 0 and u = 1 of chunk 8, waves 10 + 11 those of chunk 9.  A wave is self-contained (its own staging
+  // buffers, sums handed over by atomics), so a half needs nothing but the tile range; only these chunks' atomics double.
+  int u_lo = 0, u_hi = 2;
+  if constexpr (PAIR && NW == 12) {
+    const uint32_t lcu = (uint32_t)__builtin_amdgcn_readfirstlane((int)lcmax);  // (wave_umax's result lives in a VGPR: say it is uniform)
+    if (!(r.dbg & 4096) && lcu > 8u && lcu <= 10u && w >= 8) {  // (workgroup- and wave-uniform)
+      cw = 8 + ((w - 8) >> 1);
+      u_lo = (w - 8) & 1;
+      u_hi = u_lo + 1;
+    }
+  }
+  const unsigned long long umask = (u_hi - u_lo == 2) ? ~0ull : (0xffffffffull << (32 * u_lo));  // my tiles' pixels
   // (Measured, profiles/r03_exp_bwd_units.log: cutting a block's chunks into (chunk, pixel tile) units so that the ~9 idle
   //  waves of a block at BASELINE configs[2] take half of a chunk each does NOT pay: without the atomics the kernel goes from
   //  45 to 43 us only -- the pixel steps are issue-bound per SIMD, not latency-bound per wave -- and with twice the atomics
@@ -334,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       // two passes of 16 pixels per lane (tile u = pixel rows 4u..4u+3 of the block); kept rolled so that only one
       // D tile and no colour/feature row are live during the pixel steps
 #pragma unroll 1
-      for (int u = 0; u < 2; u++) {
+      for (int u = u_lo; u < u_hi; u++) {
         const uint32_t lmu = (uint32_t)((g == 0 ? lm0 : lm1) >> (32 * u));  // live pixels of this tile (block rows 4u .. 4u+3)
         if (lmu == 0u) continue;
         // D = dL . row for my 16 pixels of this tile, on the matrix cores.  B operand: lane (n, h) feeds channel
@@ -491,7 +505,7 @@ __global__ void __launch_bounds__(NW * 64, TWO ? 4 : 1) gm_bwd_kernel(RenderArgs
       //      rows (32 consecutive feature channels of one Gaussian = one 128-B line; 8 Gaussians x 6 geometry sums;
       //      16 Gaussians x 3 colour sums) instead of 64 different lines.  (Nothing to hand over if no pixel of the
       //      block blended anything of this group.) ----
-      if ((g == 0 ? lm0 : lm1) != 0ull) {
+      if (((g == 0 ? lm0 : lm1) & umask) != 0ull) {
         float v[9] = {a_mx * ddelx_dx, a_my * ddely_dy, -0.5f * a_cx, -0.5f * a_cy, -0.5f * a_cz, a_op, a_r, a_g, a_b};
 #pragma unroll
         for (int i = 0; i < 9; i++) v[i] += __uint_as_float(lane_xor<32>(__float_as_uint(v[i]), lane));

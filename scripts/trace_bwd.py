@@ -56,3 +56,12 @@ for a, b, n in ((4, 5, "staging"), (5, 6, "group-1 loops"), (6, 7, "group-1 out"
     if d.size:
         print(f"  per live wave {n:14s}: mean {d.mean():8.0f}  p90 {np.percentile(d, 90):8.0f}  max {d.max():8d}  (waves {d.size})")
 print("live waves per block: mean", live.sum(1).mean(), "max", live.sum(1).max())
+# per wave of the slowest blocks: cycles from "records staged" to "group 0 sums out" (the wave's whole chunk), by wave index
+order = np.argsort(-ends)[:6]
+for b in order:
+    d = np.where((rel[b, :, 9] >= 0) & (rel[b, :, 4] >= 0), rel[b, :, 9] - rel[b, :, 4], -1)
+    print(f"block {b}: duration {ends[b]}, live waves {int(live[b].sum())}, per wave (index = wave; chunks 4-7 sit on waves 7-4) chunk cycles {d[:12].tolist()}, "
+          f"chunk end {rel[b, :12, 9].tolist()}")
+med = np.argsort(ends)[len(ends) // 2]
+d = np.where((rel[med, :, 9] >= 0) & (rel[med, :, 4] >= 0), rel[med, :, 9] - rel[med, :, 4], -1)
+print(f"median block {med}: duration {ends[med]}, live waves {int(live[med].sum())}, per wave chunk cycles {d[:12].tolist()}")
