@@ -61,3 +61,8 @@ for a, b, n in ((2, 3, "staging (list barrier -> rows staged)"), (3, 4, "phase A
     d = (rel[:, :, b] - rel[:, :, a])[m]
     if d.size:
         print(f"  per wave {n:40s}: waves {d.size:5d} mean {d.mean():8.0f}  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}  max {d.max():8d}")
+# per wave of the slowest blocks: when each wave finished phase A, phase B (round 0) and reached the final barrier
+order = np.argsort(-ends)[:4]
+for b in list(order) + [int(np.argsort(ends)[len(ends) // 2])]:
+    print(f"block {b}: duration {ends[b]}; per wave  staged {rel[b, :, 3].tolist()}  phase A done {rel[b, :, 4].tolist()}  phase B done {rel[b, :, 6].tolist()}  "
+          f"round end {rel[b, :, 7].tolist()}  before final {rel[b, :, 21].tolist()}  summed {rel[b, :, 22].tolist()}")
