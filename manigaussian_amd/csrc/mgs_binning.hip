@@ -76,7 +76,7 @@ __device__ void block_exclusive_scan(uint32_t* v, int n, uint32_t* tmp, uint32_t
 // A tile's slice of L keys is cut into ns = ceil(L/seg) equal segments of seglen = ceil(L/ns) keys.
 // seg_desc[s] = {first key of segment s (absolute), its key count, tile slice start, tile slice length}.
 
-// Workgroups [0, nblk) scatter the keys of PRE_BLOCK Gaussians each (the partition the preprocess used);
+// Workgroups [0, nblk) scatter the keys of blockDim.x = pre_block() Gaussians each (the partition the preprocess used);
 // workgroup nblk publishes ranges and the segment table for the next two kernels.
 // T = tiles = sort slices.
 __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, int tiles_x, int nblk,
@@ -105,9 +105,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
   // Everything this thread reads from memory is requested NOW, in one batch: the kernel is a chain of round trips otherwise
   // (instance count -> histogram -> reservation row -> rect -> depth: five, each ~0.7 us of a 6.8 us kernel).
   // Same (view, Gaussian) partition as the forward preprocess: workgroups never straddle views.
-  const int bpv = (Pg + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int bpv = (Pg + (int)blockDim.x - 1) / (int)blockDim.x;
   const int v = (int)blockIdx.x / bpv;
-  const int gi = ((int)blockIdx.x - v * bpv) * PRE_BLOCK + tid;
+  const int gi = ((int)blockIdx.x - v * bpv) * (int)blockDim.x + tid;
   const bool work = !tables && gi < Pg;
   const int idx = work ? v * Pg + gi : 0;  // (virtual) instance owner
   const uint2 r_pre = rect[idx];
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) bin_scatter_kernel(int Pg, int T, i
     return;
   }
   for (int t = tid; t < S; t += blockDim.x) {
-    const bool first = t == tid;  // (the first PRE_BLOCK tiles came with the batch above)
+    const bool first = t == tid;  // (the first blockDim.x tiles came with the batch above)
     s_start[t] = first ? hist_pre : tile_hist[t];
     s_cnt[t] = 0;
     s_base[t] = first ? row_pre : (tables ? 0u : row[t]);  // only entries of slices this workgroup contributed to are meaningful
@@ -1012,7 +1012,8 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
   const int R = capacity;  // sizes the segment grids (upper bound)
   if (Pg <= 0) return hipSuccess;
   const int T = tiles_x * tiles_y;  // atlas tiles (tiles_y counts the rows of all V views)
-  const int nblk = V * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
+  const int pb = pre_block((size_t)Pg);
+  const int nblk = V * ((Pg + pb - 1) / pb);
   if (which == 0 && !lds_tables) {
     hipLaunchKernelGGL(bin_tables_kernel, dim3(1), dim3(1024), 0, s, T, (uint32_t)seg, (uint32_t)capacity, im.flags, status.host,
                        status.tag, im.ref_count, im.tile_hist, im.cursor, im.ranges, im.seg_base, b.seg_desc);
@@ -1025,7 +1026,7 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
   }
   if (which == 0) {
     // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(PRE_BLOCK), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(pb), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
                        tiles_x, nblk, bucket ? 0u : (uint32_t)seg, (uint32_t)capacity, g.flags, status.host, status.tag, im.ref_count, g.rect, g.depths,
                        im.tile_hist, g.blk_base, b.keys_unsorted, im.ranges, im.seg_base, b.seg_desc, im.ready, im.nonce);
     return hipGetLastError();

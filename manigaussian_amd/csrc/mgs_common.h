@@ -16,7 +16,7 @@ constexpr int CHUNK = 64;        // survivors per chunk of the render kernels (t
 #ifndef MGS_PRE_BLOCK
 #define MGS_PRE_BLOCK 1024
 #endif
-constexpr int PRE_BLOCK = MGS_PRE_BLOCK;  // Gaussians per workgroup of the forward preprocess and of the bin scatter (must match)
+constexpr int PRE_BLOCK = MGS_PRE_BLOCK;  // most Gaussians per workgroup of the forward preprocess and of the bin scatter (pre_block())
 constexpr int LDS_TILES = 4096;  // max tiles whose per-tile tables fit the binning kernels' LDS (else: tables in memory)
 constexpr int SEG_MIN = 512;     // smallest selectable sort segment (sizes the segment table)
 
@@ -101,11 +101,18 @@ struct ChunkView {
   uint2* nsurv;           // [T*4]  {survivors found by the forward (a prefix of the block's full list), first record of round 0}
 };
 
-// P: (virtual) Gaussians = V * Pg for a batch of V views; the preprocess and scatter kernels launch V * ceil(Pg / PRE_BLOCK)
+// Gaussians per workgroup of the forward preprocess and of the bin scatter for views of Pg Gaussians each.  Both kernels are
+// chains of dependent round trips on few workgroups, and every workgroup reserves its slots with one returning atomic per tile of
+// its view it has instances in -- Pg / pre_block atomics per tile counter.  Up to 131 072 Gaussians per view half-size workgroups
+// put twice as many CUs to work (preprocess 12.8 -> 10.7 us at ManiGaussian's own 16 384, 51 -> 42 us for 8 views of 100 000,
+// equal for one view of 100 000); at 500 000 the 977 atomics per counter cost 5 us more than the CUs give
+// (profiles/EXPERIMENTS.md part A0).
+inline int pre_block(size_t Pg) { return Pg <= 131072 ? PRE_BLOCK / 2 : PRE_BLOCK; }
+// P: (virtual) Gaussians = V * Pg for a batch of V views; the preprocess and scatter kernels launch V * ceil(Pg / pre_block(Pg))
 // workgroups (a workgroup never straddles views), and blk_base has one row per launched workgroup.
 inline size_t preprocess_blocks(size_t P, int V) {
-  const size_t v = V > 0 ? (size_t)V : 1, Pg = (P + v - 1) / v;
-  return v * ((Pg + PRE_BLOCK - 1) / PRE_BLOCK);
+  const size_t v = V > 0 ? (size_t)V : 1, Pg = (P + v - 1) / v, pb = (size_t)pre_block(Pg);
+  return v * ((Pg + pb - 1) / pb);
 }
 inline GeomView carve_geom(void* p, int P, int M, int T, int V, size_t* total) {
   Carver c(p);

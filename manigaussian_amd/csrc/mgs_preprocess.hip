@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     if (threadIdx.x == 0 && s_total_ref && a.ref_count) atomicAdd(a.ref_count, s_total_ref);
     if (threadIdx.x == 0 && s_pref) atomicOr(&g.flags[FLAG_PREFILTERED], 1u);
     // reserve this workgroup's slots inside every slice it contributes to; the bin scatter (same
-    // PRE_BLOCK partition of the Gaussians) reads the offsets back
+    // blockDim partition of the Gaussians) reads the offsets back
     uint32_t* __restrict__ row = a.blk_base + (size_t)blk * S;
     for (int t = threadIdx.x; t < S; t += blockDim.x) {
       const uint32_t c = s_hist[t];
@@ -454,8 +454,9 @@ hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t
     FwdPreArgs b = a;
     // one zeroing workgroup per 16 K float4 (16 stores per thread), at most 128
     b.zero_blocks = b.zero_ptr ? (int)std::min<size_t>(128, (b.zero_f4 + 16383) / 16384) : 0;
-    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + PRE_BLOCK - 1) / PRE_BLOCK) + 1 + b.zero_blocks),
-                       dim3(PRE_BLOCK), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, b, g, radii);
+    const int pb = pre_block((size_t)a.Pg);
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + pb - 1) / pb) + 1 + b.zero_blocks),
+                       dim3(pb), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, b, g, radii);
   } else
     hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(a.V * ((a.Pg + 255) / 256)), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();
@@ -686,7 +687,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdPreArgs a) {
 
 hipError_t launch_preprocess_bwd(const BwdPreArgs& a, hipStream_t s) {
   if (a.P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+  // one wave per workgroup for small sets: 256 single-wave workgroups reach every CU at ManiGaussian's 16 384 Gaussians
+  // (8.4 -> 7.8 us by the stage timers; no difference from 100 000 Gaussians up)
+  const int bb = a.P <= 32768 ? 64 : 256;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + bb - 1) / bb), dim3(bb), 0, s, a);
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #   bench      python bench.py (the driver's default command) + the driver's short form (--steps 20 --warmup 5)
 #   configs    bench lines of c2, c5shape, ref16k, views 4/8, c4, c5
 #   stats      rocprofv3 --kernel-trace --stats of the default bench (graph and eager-st)
+#   cfgstats   rocprofv3 --kernel-trace --stats of c2, c5shape and ref16k (eager-st)
 #   pmc        the six counter passes (one group per pass) -> sq_counters.json
 #   trace      s_memtime timelines of the render kernels and of the bucket-rank binning
 #   extra      $EXTRA_CMD (a shell command), output -> $OUT/extra.log
@@ -31,7 +32,7 @@ print(c['name'], c['P'], f\"{c['W']}x{c['H']}\", 'renders/gpu', c['renders_per_s
       'ref_kernels', {k: v for k, v in (j.get('reference_kernels_same_gpu') or {}).items() if k in ('ms_per_step', 'this_library_over_reference_kernels', 'note')},
       'binding', j.get('host_binding'))
 "; }
-for W in golden quick tests host pmc bench configs stats trace extra; do
+for W in golden quick tests host pmc bench configs stats cfgstats trace extra; do
   want "$@" || continue
   case $W in
   golden)
@@ -64,6 +65,12 @@ for W in golden quick tests host pmc bench configs stats trace extra; do
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$m -o stats -- python bench.py --mode $m --only-mode --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench_rocprof_$m.log 2>&1
       python scripts/top_kernels.py $OUT/stats_$m
       find $OUT/stats_$m -name "*kernel_trace.csv" -delete
+    done ;;
+  cfgstats)
+    for c in ${STATS_CONFIGS:-c2 c5shape ref16k}; do
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o stats -- python bench.py --config $c --mode eager-st --only-mode --steps 100 --warmup 20 --no-cpu-baseline --no-reference-kernels > $OUT/bench_rocprof_$c.log 2>&1
+      python scripts/top_kernels.py $OUT/stats_$c
+      find $OUT/stats_$c -name "*kernel_trace.csv" -delete
     done ;;
   pmc)
     H=$(python -c "from manigaussian_amd import _lib; print(_lib.build_id())")
