@@ -92,6 +92,11 @@ CASES = {
     "slice_8193_two_rounds": dict(P=8193, W=16, exact=True),
     "slice_16384_in_registers": dict(P=16384, W=16, exact=True),
     "slice_16385_streamed": dict(P=16385, W=16, exact=True),
+    # the preprocess / scatter partition (csrc/mgs_common.h pre_block): 512 Gaussians per workgroup up to 131 072, 1 024 beyond;
+    # a last workgroup holding one Gaussian
+    "partition_513_last_workgroup_of_one": dict(P=513, W=32),
+    "partition_131072_workgroups_of_512": dict(P=131072, W=64),
+    "partition_131073_workgroups_of_1024": dict(P=131073, W=64),
     "ragged_tiles_80x48_30000": dict(P=30000, W=80, H=48),
     "many_tiles_256x256_200000": dict(P=200000, W=256),
 }
