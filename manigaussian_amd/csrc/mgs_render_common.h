@@ -34,26 +34,34 @@ __device__ __forceinline__ f32x2 exp_ocml_unclamped2(f32x2 x) {
                __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)e.y)};
 }
 // The exponent of one (pixel, Gaussian) pair, -1/2 (cx dx^2 + cz dy^2) - cy dx dy (forward.cu:345-347, backward.cu:456-458).
-// EVERY kernel that takes the pair's two decisions (power > 0 -> skip, alpha < 1/255 -> skip) evaluates it through these two
+// EVERY kernel that takes the pair's two decisions (power > 0 -> skip, alpha < 1/255 -> skip) evaluates it through these
 // functions: the forward and every form of the backward must round it identically, or a pair within an ulp of a threshold is
 // blended by one and skipped by the other (the transmittances and suffix sums of the backward are then those of another
-// blend).  Written with explicit operations and contraction off: left to the compiler, the scalar and the packed expression
-// are fused differently (mul + sub against one fma for the last step).  mgs_selftest compares the two forms bit for bit.
+// blend).  The roundings are THE REFERENCE KERNELS' as this toolchain compiles them (round 6; oracle/Makefile's build, read off
+// the ISA of renderCUDA forward and backward at feature widths 3, 8 and 32 -- the same everywhere): the two squares are packed
+// by the vectoriser and therefore NOT contracted,
+//     t = ((dx cx) dx) + ((dy cz) dy)          v_pk_mul, v_pk_mul, v_add      (five roundings)
+//     power = fma(t, -1/2, -((dx cy) dy))      v_mul, v_mul, v_fma
+// Rounds 3-5 had t as fma(cx dx, dx, (cz dy) dy): up to a few ulps away, which moved an alpha across 1/255 in one pair of one
+// scene in 1 200 (tests/tools/fuzz_parity.py seed 101 case 234: 2e-3 on one pixel) -- with the reference's own sequence alpha is
+// the reference's bit for bit (bit-identical conic, mean and opacity: tests/test_gpu_parity.py; bit-identical exp: above).
+// Written with explicit operations and contraction off: left to the compiler, the scalar and the packed expression are fused
+// differently.  mgs_selftest compares the forms bit for bit, and the pair of that scene against the reference's bits.
 __device__ __forceinline__ float gauss_power(float cx, float cy, float cz, float dx, float dy) {
 #pragma clang fp contract(off)
-  const float t = __builtin_fmaf(cx * dx, dx, (cz * dy) * dy);
+  const float t = (cx * dx) * dx + (cz * dy) * dy;
   return __builtin_fmaf(-0.5f, t, -((cy * dx) * dy));
 }
 __device__ __forceinline__ f32x2 gauss_power2(float cx, float cy, float cz, f32x2 dx, float dy) {
 #pragma clang fp contract(off)
   const float yy = (cz * dy) * dy;
-  const f32x2 t = __builtin_elementwise_fma(cx * dx, dx, f32x2{yy, yy});
+  const f32x2 t = (cx * dx) * dx + f32x2{yy, yy};
   return __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, t, -((cy * dx) * dy));
 }
 // ... and with two Gaussians (conics) as well as two offsets: the forward's double steps
 __device__ __forceinline__ f32x2 gauss_power2v(f32x2 cx, f32x2 cy, f32x2 cz, f32x2 dx, f32x2 dy) {
 #pragma clang fp contract(off)
-  const f32x2 t = __builtin_elementwise_fma(cx * dx, dx, (cz * dy) * dy);
+  const f32x2 t = (cx * dx) * dx + (cz * dy) * dy;
   return __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, t, -((cy * dx) * dy));
 }
 template <bool FAST>

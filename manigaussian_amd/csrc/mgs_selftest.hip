@@ -98,6 +98,13 @@ __global__ void selftest_kernel(int* result) {
       if (__float_as_uint(p3.x) != __float_as_uint(gauss_power(cx, cy, cz, dx0, dy)) ||
           __float_as_uint(p3.y) != __float_as_uint(gauss_power(cz, -cy, cx, dy, dx0))) bad |= 1 << 29;
     }
+    {  // known answer: the pair whose alpha sits 1 ulp under 1/255 in the reference's kernels (fuzz_parity seed 101 case 234,
+       // pixel (77, 5), Gaussian 56): the reference's roundings give power 0xbf9e36a4 and alpha 0x3b808080 < 1/255 = 0x3b808081
+      const float x = __uint_as_float(0x42836bbau), y = __uint_as_float(0xbfaa7610u), cx = __uint_as_float(0x3d3ade4fu);
+      const float cy = __uint_as_float(0xbd8604a9u), cz = __uint_as_float(0x3e1993fdu), o = __uint_as_float(0x3c5d264cu);
+      const float p = gauss_power(cx, cy, cz, x - 77.0f, y - 5.0f);
+      if (__float_as_uint(p) != 0xbf9e36a4u || __float_as_uint(o * exp_ocml_unclamped(p)) != 0x3b808080u) bad |= 1 << 29;
+    }
   }
   {  // the pair's pixel offsets: the two-pixel backward forms them as ONE packed subtraction from the exact pixel coordinates,
      // which must equal the forward's and the one-pixel form's scalar `ex - px` bit for bit -- also where |dx| crosses a power
