@@ -114,6 +114,8 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--fast-exp", type=int, default=None, help="MgsOptions.fast_exp of every call (default: the library's)")
     ap.add_argument("--bin-mode", type=int, default=None, help="MgsOptions.bin_mode of every call (0: binning tables in memory)")
+    ap.add_argument("--dbg", type=int, default=None, help="MgsOptions.dbg of every call (diagnostic A/B switches, e.g. 32768 = the bin "
+                                                          "scatter launch writes the keys instead of the preprocess)")
     ap.add_argument("--gm-waves", type=int, default=None, help="MgsOptions.gm_waves of every call (render backward: 12 = "
                                                                "two pixels per step, the default; 16 / 8 = the one-pixel forms)")
     ap.add_argument("--forward-mode", default="async", choices=["async", "safe", "blocking"],
@@ -349,6 +351,8 @@ def main():
         _lib.set_option("fast_exp", args.fast_exp)
     if args.bin_mode is not None:
         _lib.set_option("bin_mode", args.bin_mode)
+    if args.dbg is not None:
+        _lib.set_option("dbg", args.dbg)
     if args.gm_waves is not None:
         _lib.set_option("gm_waves", args.gm_waves)
     # The package default ("safe") never sizes a workspace speculatively; a training loop that wants a step without any

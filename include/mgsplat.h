@@ -141,6 +141,12 @@ size_t mgs_geom_bytes(int P, int M, int W, int H);
 size_t mgs_img_bytes(int W, int H);
 size_t mgs_binning_bytes(int R, int W, int H, int F);  /* F = feature channels rendered (0 if none); worst-case chunk pool */
 size_t mgs_binning_bytes2(int R, int chunk_pool, int W, int H, int F);  /* explicit pool (0: worst case) */
+/* Optional: bytes to ADD to the binning workspace (behind mgs_binning_bytes2 / mgs_views_binning_bytes2) so that the forward
+ * preprocess writes the tile keys itself and the bin scatter launch disappears (P Gaussians per view, V views, V = 1 for the
+ * single-view calls): tiles x P keys of 8 bytes, 51 MB at 100 000 Gaussians on 128 x 128.  0: not offered for this shape (more
+ * than 4 096 tiles, or more than 128 MB).  A workspace without them works as before; a capacity of at least tiles x P / 2
+ * instances (every worst-case workspace) gets the same path without them. */
+size_t mgs_binning_direct_extra(int P, int V, int W, int H);
 int mgs_chunk_pool_max(int R, int W, int H);           /* chunk records of the worst case: every chunk of every 8x8 block */
 size_t mgs_backward_scratch_bytes(int P, int M, int F);
 
@@ -344,6 +350,11 @@ int mgs_debug_geom_layout(int P, int M, int W, int H, size_t* depths, size_t* re
  * (RAST/cuda_rasterizer/rasterizer_impl.cu:306-320). */
 int mgs_debug_binning_layout(const MgsRasterArgs* a, int32_t V, size_t* keys_unsorted, size_t* point_list, size_t* img_ranges,
                              int32_t* capacity);
+/* ... and, when the forward preprocess wrote the keys itself ("direct" binning: the bucket rank, bin_mode 2, on a workspace
+ * that has room for tiles x P keys -- see mgs_binning_direct_extra), where: *stride = P and tile t's unordered slice lies at
+ * u64[*keys / 8 + t * P ...] of the binning workspace (its length is the tile's range); *stride = 0: the bin scatter kernel wrote
+ * the compact keys_unsorted above. */
+int mgs_debug_direct_keys(const MgsRasterArgs* a, int32_t V, size_t* keys, int32_t* stride);
 
 /* Diagnostic: with MgsOptions.dbg = 256 the render forward stamps s_memtime per (workgroup < 512, wave, phase);
  * this copies the 512 * 16 * 24 uint64 stamps of the last forward to `host` (scripts/trace_fwd.py prints the timeline). */

@@ -103,13 +103,19 @@ def _shape_sizes(L, P, M, W, H):
     return v
 
 
-def _bin_bytes(L, cap, pool, W, H, F):
-    k = (cap, pool, W, H, F)
+def _bin_bytes(L, cap, pool, W, H, F, P=0):
+    """Bytes of the binning workspace; P > 0: plus the room in which the forward preprocess writes the tile keys itself (no bin
+    scatter launch; include/mgsplat.h mgs_binning_direct_extra) where the library offers it for the shape."""
+    k = (cap, pool, W, H, F, P)
     v = _BIN_BYTES.get(k)
     if v is None:
         if len(_BIN_BYTES) > 4096:
             _BIN_BYTES.clear()
-        v = _BIN_BYTES[k] = L.mgs_binning_bytes2(cap, pool, W, H, F)
+        v = L.mgs_binning_bytes2(cap, pool, W, H, F)
+        if P > 0:
+            extra = L.mgs_binning_direct_extra(P, 1, W, H)
+            v = _up256(v) + extra if extra else v
+        _BIN_BYTES[k] = v
     return v
 
 
@@ -406,7 +412,9 @@ def _forward(background, means3D, colors, language_feature, opacity, scales, rot
         # ONE allocation for the three opaque workspaces [geom | img | binning] (each a multiple of 256 bytes), one for the
         # two images; radii and the backward's gradient buffer have lifetimes of their own
         gb, ib = _shape_sizes(L, P, M, W, H)
-        bb = _bin_bytes(L, cap, pool, W, H, F)
+        # (room for the keys of the direct binning: a worst-case capacity covers them by itself, and the blocking path's carving
+        #  is derived from the byte count -- extra bytes would only raise its capacity)
+        bb = _bin_bytes(L, cap, pool, W, H, F, P if lazy and cap != cap_worst else 0)
         if _SPLIT_WORKSPACES:
             ws3 = (torch.empty((gb,), **u8), torch.empty((ib,), **u8), torch.empty((bb,), **u8))
             p_geom, p_img, p_bin = ws3[0].data_ptr(), ws3[1].data_ptr(), ws3[2].data_ptr()

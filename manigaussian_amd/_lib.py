@@ -64,6 +64,7 @@ _EXPORTS = {
     "mgs_img_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
     "mgs_binning_bytes": (c_sz, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mgs_binning_bytes2": (c_sz, [ctypes.c_int] * 5),
+    "mgs_binning_direct_extra": (c_sz, [ctypes.c_int] * 4),
     "mgs_chunk_pool_max": (ctypes.c_int, [ctypes.c_int] * 3),
     "mgs_forward_result": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_fp, ctypes.POINTER(c_i32),
                                           ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
@@ -110,6 +111,7 @@ _EXPORTS = {
     "mgs_debug_geom_layout": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.POINTER(c_sz)] * 4),
     "mgs_debug_binning_layout": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32] + [ctypes.POINTER(c_sz)] * 3 +
                                  [ctypes.POINTER(c_i32)]),
+    "mgs_debug_direct_keys": (ctypes.c_int, [ctypes.POINTER(MgsRasterArgs), c_i32, ctypes.POINTER(c_sz), ctypes.POINTER(c_i32)]),
     "mgs_debug_read_trace": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bwd": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "mgs_debug_read_trace_bin": (ctypes.c_int, [ctypes.c_void_p, c_sz]),

@@ -235,9 +235,33 @@ static BinShape bin_shape(const MgsRasterArgs* a, int T, int F) {
   return s;
 }
 
+// Direct binning (mgs_common.h): where the forward preprocess of THIS call may write its keys -- inside the caller's binning
+// workspace: the two key arrays if the capacity covers T * Pg keys (the worst-case workspaces of the default forward mode do),
+// else bytes the caller added behind the carved arrays (mgs_binning_direct_extra); nullptr: the bin scatter kernel writes
+// compact slices as before.  MgsOptions.dbg & 32768 switches it off (A/B).
+static uint64_t* direct_region(const MgsRasterArgs* a, const BinShape& bs, int T, int F, size_t P, int V, const Options& o) {
+  if (!bucket_rank(o, T) || (o.dbg & 32768)) return nullptr;
+  const size_t need = direct_keys_needed(P, V, T);
+  if (!need) return nullptr;
+  size_t total = 0;
+  const BinView b = carve_binning(a->binning, bs.cap, T, F, bs.pool, nullptr, &total);
+  const size_t span = (size_t)(reinterpret_cast<const char*>(b.point_list) - reinterpret_cast<const char*>(b.keys_unsorted));
+  if (span >= need * sizeof(uint64_t)) return b.keys_unsorted;  // (the sorted-key array is unused by the bucket rank)
+  const size_t off = (total + 255) & ~(size_t)255;
+  if (need <= DIRECT_MAX_KEYS && a->binning_bytes >= off + need * sizeof(uint64_t))
+    return reinterpret_cast<uint64_t*>(static_cast<char*>(a->binning) + off);
+  return nullptr;
+}
+size_t mgs_binning_direct_extra(int P, int V, int W, int H) {
+  const int v = V > 0 ? V : 1;
+  const size_t need = direct_keys_needed((size_t)(P > 0 ? P : 0) * v, v, num_tiles(W, H) * v);
+  return need && need <= DIRECT_MAX_KEYS ? need * sizeof(uint64_t) + 256 : 0;
+}
+
 // Everything of the forward before the instance count is known: (zero tables,) preprocess.
+// direct_keys: see direct_region (nullptr from the two-call path: its second call may come with another workspace).
 static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t* radii, hipStream_t stream, GeomView& g,
-                              ImgView& im, bool& lds) {
+                              ImgView& im, bool& lds, uint64_t* direct_keys = nullptr) {
   if (!radii || !a->opacities) { set_error("radii/opacities must be non-NULL"); return MGS_ERR_INVALID_ARG; }
   if (!a->geom || a->geom_bytes < mgs_geom_bytes(a->P, a->M, a->W, a->H) || !a->img ||
       a->img_bytes < mgs_img_bytes(a->W, a->H)) {
@@ -282,6 +306,7 @@ static int enqueue_preprocess(const MgsRasterArgs* a, const Options& o, int32_t*
   p.tile_hist = im.tile_hist;
   p.blk_base = lds ? g.blk_base : nullptr;
   p.ref_count = im.ref_count;
+  p.direct_keys = lds ? direct_keys : nullptr; p.direct_stride = (uint32_t)a->P;
   { StageTimer t(ST_PREPROCESS, stream);
     MGS_STAGE(launch_preprocess_fwd(p, g, radii, stream), "preprocess", a->debug, stream); }
   return MGS_OK;
@@ -370,8 +395,10 @@ static RenderArgs render_args(const MgsRasterArgs* a, const Options& o, const Ge
 
 // Binning + render.  R: instance count if the host knows it (checked against the capacity here), else -1.
 // status: where the device reports (see StatusSink), host == nullptr: nowhere.
+// direct_keys: the preprocess of this call wrote the keys there (direct_region); nullptr: the bin scatter kernel runs.
 static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const int32_t* radii, float* out_color,
-                          float* out_feature, StatusSink status, unsigned long long nonce, hipStream_t stream) {
+                          float* out_feature, StatusSink status, unsigned long long nonce, hipStream_t stream,
+                          uint64_t* direct_keys = nullptr) {
   const int F = a->include_feature ? a->F : 0;
   const int T = num_tiles(a->W, a->H);
   const bool lds = lds_tables(o, T);
@@ -379,6 +406,7 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   ImgView im = carve_img(a->img, a->W, a->H, nullptr);
   g.flags = im.flags;
   im.nonce = nonce;  // (0: the caller has already looked at the preprocess's outcome)
+  im.direct_keys = lds ? direct_keys : nullptr; im.direct_stride = (uint32_t)a->P;
   const BinShape bs = bin_shape(a, T, F);
   if (!a->binning || bs.cap < 0 || (R >= 0 && R > bs.cap)) {
     set_error("binning workspace too small: %zu bytes hold %d instances, need %d", a->binning_bytes, bs.cap, R);
@@ -480,8 +508,9 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
   const int F = a->include_feature ? a->F : 0;
   const BinShape bs = bin_shape(a, num_tiles(a->W, a->H), F);
   if (!a->binning || bs.cap < 0) { set_error("binning workspace missing or smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  uint64_t* const dk = direct_region(a, bs, num_tiles(a->W, a->H), F, (size_t)a->P, 1, o);
   for (int attempt = 0;; attempt++) {
-  rc = enqueue_preprocess(a, o, radii, stream, g, im, lds);
+  rc = enqueue_preprocess(a, o, radii, stream, g, im, lds, dk);
   if (rc) return rc;
   uint32_t R = 0, fl = 0;
   if (!host_status || a->debug) {
@@ -498,13 +527,13 @@ int mgs_rasterize_forward(const MgsRasterArgs* a, int32_t* radii, float* out_col
       volatile uint64_t* hs = host_status;
       hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
     }
-    return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, 0ull, stream);
+    return enqueue_render(a, o, (int)R, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, 0ull, stream, dk);
   }
   // sync-free: everything is enqueued; the binning kernel stores {tag, reference count} and {tag, flags, R} to the mapped host
   // words as soon as the preprocess is done, and refuses to bin (empty ranges, zero segments) when R exceeds the capacity.
   volatile uint64_t* hs = host_status;
   hs[0] = kStatusPending; hs[1] = kStatusPending; hs[2] = kStatusPending;
-  rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, im.nonce, stream);
+  rc = enqueue_render(a, o, -1, radii, out_color, out_feature, StatusSink{host_status, a->status_tag}, im.nonce, stream, dk);
   if (rc) return rc;
   if (a->async_forward) { *num_rendered = -1; return MGS_OK; }  // the caller reads mgs_forward_result later
   // Wait for the PREPROCESS only: word 0 arrives when the bin scatter starts; binning and render run on while this call
@@ -764,6 +793,9 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
     p.zero_f4 = a->bwd_accum_bytes / 16;
   }
   const bool lds = lds_tables(o, at.T);
+  im.direct_keys = lds ? direct_region(a, bs, at.T, F, (size_t)a->P * V, V, o) : nullptr;
+  im.direct_stride = (uint32_t)a->P;
+  p.direct_keys = im.direct_keys; p.direct_stride = im.direct_stride;
   const bool handshake = lds && !o.table_init;  // (see enqueue_preprocess)
   if (!handshake) MGS_HIP(launch_zero_bytes(im.flags, im.zero_bytes, stream), "zero flags + tile tables");
   p.tile_hist = im.tile_hist; p.blk_base = lds ? g.blk_base : nullptr; p.ref_count = im.ref_count;
@@ -937,6 +969,22 @@ int mgs_debug_binning_layout(const MgsRasterArgs* a, int32_t V, size_t* keys_uns
   if (point_list) *point_list = (size_t)(reinterpret_cast<char*>(b.point_list) - base);
   if (img_ranges) *img_ranges = (size_t)(reinterpret_cast<char*>(im.ranges) - base);
   if (capacity) *capacity = bs.cap;
+  return MGS_OK;
+}
+
+int mgs_debug_direct_keys(const MgsRasterArgs* a, int32_t V, size_t* keys, int32_t* stride) {
+  if (!a || a->W <= 0 || a->H <= 0 || !keys || !stride) { set_error("direct_keys: bad argument"); return MGS_ERR_INVALID_ARG; }
+  *keys = 0; *stride = 0;
+  if (a->P <= 0 || !a->binning) return MGS_OK;
+  const int F = a->include_feature ? a->F : 0;
+  const int v = V > 0 ? V : 1;
+  const int T = V > 0 ? atlas_of(a->W, a->H, V).T : num_tiles(a->W, a->H);
+  const BinShape bs = bin_shape(a, T, F);
+  if (bs.cap < 0) { set_error("direct_keys: binning workspace smaller than its fixed part"); return MGS_ERR_WORKSPACE; }
+  const uint64_t* dk = direct_region(a, bs, T, F, (size_t)a->P * v, v, options_of(a));
+  if (!dk) return MGS_OK;
+  *keys = (size_t)(reinterpret_cast<const char*>(dk) - static_cast<const char*>(a->binning));
+  *stride = a->P;
   return MGS_OK;
 }
 

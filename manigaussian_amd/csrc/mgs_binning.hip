@@ -637,6 +637,7 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v) { return ~wave_umax(~v
     }                                                                                     \
   }
 
+static_assert(LDS_TILES <= BK_CAP2 && BK_BIG_LIST >= 64 + 16, "direct binning scans the tile histogram in BkShared::sid / biglist");
 struct BkShared {
   uint64_t sk[BK_CAP2 + 8];       // the round's keys grouped by level-2 bucket (+ 8: an owner reads 8 slots from its start)
   uint32_t sid[BK_CAP2];          // ... their ids in order
@@ -690,10 +691,28 @@ __device__ __forceinline__ void bk_owner_sort(BkShared& S, uint32_t b0, uint32_t
     if ((uint32_t)i < c) S.sid[b0 + r[i]] = (uint32_t)kk[i];
 }
 
+// Direct binning (mgs_common.h, ImgView::direct_keys): the preprocess wrote tile t's keys at keys[t * stride ...]; there was no
+// bin scatter launch, so this kernel does what that kernel's table workgroup did -- every workgroup scans the tile histogram
+// for its own slice of the compact id list, workgroup 0 publishes `ranges` and reports {tag, flags, R} and the reference's count
+// to the host (same words, same order: see bin_scatter_kernel) and resets the preprocess's hand-shake word.
+struct BkDirect {
+  const uint64_t* keys;  // nullptr: the scatter kernel ran; ranges / keys_unsorted are its outputs
+  uint32_t stride;
+  uint32_t capacity;
+  const uint32_t* tile_hist;
+  const uint32_t* flags;
+  const uint32_t* ref_count;
+  uint2* ranges_out;
+  uint64_t* host_status;
+  uint32_t status_tag;
+  unsigned long long* ready;
+  unsigned long long nonce;
+};
+
 __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int split, int dbg, const uint2* __restrict__ ranges,
                                                                      const uint64_t* __restrict__ keys_unsorted,
                                                                      uint32_t* __restrict__ point_list,
-                                                                     unsigned long long* hs_fail_mark) {
+                                                                     unsigned long long* hs_fail_mark, BkDirect d) {
   __shared__ BkShared S;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,15 +725,55 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
   // (kernel boundary); cleared here so that a replayed HIP graph -- same buffer, same nonce -- does not see a stale failure
   if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;
   if (dbg && tid < BK_TRACE_EVENTS && blockIdx.x < 1024) g_bk_trace[(size_t)blockIdx.x * BK_TRACE_EVENTS + tid] = 0ull;
-  if (tile >= T) return;
+  uint2 rng;
+  if (d.keys) {  // (grid-uniform)
+    // a preprocess workgroup gave up waiting for the zeroed tables (ready[1] == this forward's nonce): the histogram is
+    // incomplete, nothing is binned, flag bit 1 tells the host why.  (The mark is read by every workgroup of this launch; the
+    // render forward, next in the chain, clears it.)
+    const bool hs_failed = d.ready != nullptr && d.nonce != 0ull && d.ready[1] == d.nonce;
+    const uint32_t R = hs_failed ? 0xffffffffu : d.flags[FLAG_NUM_RENDERED];
+    const bool wg0 = blockIdx.x == 0;
+    if (wg0 && tid == 0) {
+      if (d.ready) *d.ready = 0ull;  // the hand-shake word: "not ready" for the next launch on this buffer
+      if (d.host_status) {           // word 2 = {tag, the reference's count} first, then word 0 = {tag, flags, R} with release order
+        __hip_atomic_store(d.host_status + 2, ((uint64_t)(d.status_tag & 0xffffu) << 48) | (uint64_t)(hs_failed ? 0u : *d.ref_count),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(d.host_status, ((uint64_t)(d.status_tag & 0xffffu) << 48) |
+                           ((uint64_t)((d.flags[FLAG_PREFILTERED] & 0xfffdu) | (hs_failed ? 2u : 0u)) << 32) | (hs_failed ? 0u : R),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (R > d.capacity) {  // the id list cannot hold the instances (or the hand-shake failed): "nothing binned", the caller retries
+      if (wg0) for (int t = tid; t < T; t += BK_THREADS) d.ranges_out[t] = make_uint2(0u, 0u);
+      return;
+    }
+    if (tile >= T) return;
+    if (T <= 64) {  // (grid-uniform) the 64 tiles of a 128 x 128 image: every wave scans the histogram in its own registers
+      const uint32_t x = lane < T ? d.tile_hist[lane] : 0u;
+      const uint32_t incl = wave_incl_scan_add_u32(x);
+      if (wg0 && wv == 0 && lane < T) d.ranges_out[lane] = make_uint2(incl - x, incl);
+      rng = make_uint2(bcast_lane_u32(incl - x, tile), bcast_lane_u32(incl, tile));
+    } else {
+      uint32_t* const sc = S.sid;  // (T <= LDS_TILES <= BK_CAP2 words; the array's own use starts many barriers later)
+      for (int t = tid; t < T; t += BK_THREADS) sc[t] = d.tile_hist[t];
+      __syncthreads();
+      block_exclusive_scan(sc, T, S.biglist, &S.gath);
+      if (wg0) for (int t = tid; t < T; t += BK_THREADS) d.ranges_out[t] = make_uint2(sc[t], sc[t] + d.tile_hist[t]);
+      const uint32_t start = sc[tile];
+      rng = make_uint2(start, start + d.tile_hist[tile]);
+      __syncthreads();  // (every read of sc is done: S.biglist / S.gath / S.sid go back to their own uses)
+    }
+  } else {
+    if (tile >= T) return;
+    rng = ranges[tile];
+  }
   MGS_BKTRACE(0);
-  const uint2 rng = ranges[tile];
   const uint32_t L = rng.y - rng.x;
   if (L == 0u) return;
   const bool small = L <= (uint32_t)BK_SMALL;   // one workgroup, one round, no level 1
   if (small && q != 0u) return;
   MGS_BKTRACE(1);
-  const uint64_t* __restrict__ src = keys_unsorted + rng.x;
+  const uint64_t* __restrict__ src = d.keys ? d.keys + (size_t)tile * d.stride : keys_unsorted + rng.x;
   uint32_t* __restrict__ dst = point_list + rng.x;
   const bool inreg = L <= (uint32_t)BK_INREG;   // (workgroup-uniform)
   const int kpt = inreg ? (int)((L + BK_THREADS - 1) / BK_THREADS) : 0;
@@ -1024,6 +1083,8 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
                        g.rect, g.depths, im.ranges, im.cursor, b.keys_unsorted);
     return hipGetLastError();
   }
+  const bool direct = bucket && lds_tables && im.direct_keys != nullptr;  // the preprocess wrote the keys: no scatter launch
+  if (which == 0 && direct) return hipSuccess;
   if (which == 0) {
     // the extra workgroup publishes ranges (all-empty when R == 0) and the segment table
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(nblk + 1), dim3(pb), 3 * sizeof(uint32_t) * (size_t)T, s, Pg, T,
@@ -1041,8 +1102,13 @@ hipError_t launch_bin_segsort(int which, bool lds_tables, bool bucket, const Geo
       while (split < 4 && T * split * 2 <= 256) split *= 2;
       if (dbg & 0x7000) split = 1 << (((dbg >> 12) & 7) - 1);  // (experiments: MgsOptions.dbg bits 12-14 = 1 + log2 of the parts)
       const int grid = ((T + 7) / 8) * 8 * split;
+      BkDirect d{};
+      if (direct)
+        d = BkDirect{im.direct_keys, im.direct_stride, (uint32_t)capacity, im.tile_hist, g.flags, im.ref_count, im.ranges,
+                     status.host, status.tag, im.ready, im.nonce};
+      // (direct: the failure mark is still being read by this launch's workgroups -- the render forward clears it)
       hipLaunchKernelGGL(bin_bucket_emit_kernel, dim3(grid), dim3(BK_THREADS), 0, s, T, split, dbg & 256, im.ranges, b.keys_unsorted,
-                         b.point_list, im.ready ? im.ready + 1 : nullptr);
+                         b.point_list, (im.ready && !direct) ? im.ready + 1 : nullptr, d);
     }
     return hipGetLastError();
   }

@@ -73,7 +73,22 @@ struct ImgView {
   // kernel (next in the chain) stores 0 again.  Replaces a separate zero-fill launch per forward.
   unsigned long long* ready;   // [2]: [0] the hand-shake word, [1] = the launch's nonce if a workgroup gave up waiting for it
   unsigned long long nonce;    // host side only: the nonce of the forward in flight on this workspace (0: none)
+  // host side only, "direct" binning (round 6): the forward preprocess of THIS call wrote the keys itself, tile t's unsorted
+  // slice at direct_keys[t * direct_stride ...] (nullptr: the bin scatter kernel writes them, compact, into BinView::keys_unsorted)
+  uint64_t* direct_keys;
+  uint32_t direct_stride;
 };
+// Direct binning: a tile holds every Gaussian of its view at most once, so a slice of Pg keys per tile can never overflow and
+// the preprocess can write a Gaussian's keys the moment it has reserved its workgroup's slots -- no prefix over the tiles, hence
+// no scatter kernel (5 us + a kernel boundary per forward).  The bucket rank (mgs_binning.hip) reads the strided slices, scans
+// the tile histogram itself and publishes ranges and the status words.  T * Pg keys: 51 MB at BASELINE configs[2], 8 MB at
+// ManiGaussian's own shape; offered up to DIRECT_MAX_KEYS (128 MB) and whenever the caller's capacity already covers it (the
+// worst-case workspaces of the default forward mode do).  Returns the keys the region must hold, 0: not applicable.
+constexpr size_t DIRECT_MAX_KEYS = (size_t)16 << 20;
+inline size_t direct_keys_needed(size_t P, int V, int T) {
+  const size_t v = V > 0 ? (size_t)V : 1, Pg = (P + v - 1) / v;
+  return (T > 0 && T <= LDS_TILES && P > 0) ? (size_t)T * Pg : 0;
+}
 
 struct BinView {
   uint64_t* keys_unsorted;  // [R]  (depth bits << 32 | id), tile-major, unordered inside a tile
@@ -148,6 +163,8 @@ inline ImgView carve_img(void* p, int W, int H, size_t* total) {
   v.ready = c.take<unsigned long long>(2);
   v.cursor = c.take<uint32_t>(S);
   v.nonce = 0ull;
+  v.direct_keys = nullptr;
+  v.direct_stride = 0u;
   if (total) *total = c.total();
   return v;
 }
@@ -241,6 +258,8 @@ struct FwdPreArgs {
   unsigned long long* ready;  // ImgView::ready
   unsigned long long nonce;   // this launch's (non-zero) nonce; 0: the tables were zeroed by an earlier launch, no hand-shake
   int wg0_delay;              // test hook (MgsOptions.dbg & 512): workgroup 0 sleeps this many x ~3 us before it zeroes the tables
+  uint64_t* direct_keys;      // direct binning (ImgView::direct_keys): this launch writes the keys; nullptr: the bin scatter does
+  uint32_t direct_stride;     // ... keys per tile slice (= Pg)
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int prefiltered, tight_bins;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;

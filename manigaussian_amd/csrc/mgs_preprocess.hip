@@ -249,11 +249,18 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
   const float tanfovx = batch ? a.cam[v].tanfovx : a.tanfovx, tanfovy = batch ? a.cam[v].tanfovy : a.tanfovy;
   const float focal_x = batch ? a.cam[v].focal_x : a.focal_x, focal_y = batch ? a.cam[v].focal_y : a.focal_y;
   const int S = T;  // sort slices = tiles
+  // direct binning (FwdPreArgs::direct_keys): two more tables behind the histogram -- this workgroup's reserved offset inside
+  // every tile slice, and its write cursor there
+  uint32_t* const s_base = s_hist + S;
+  uint32_t* const s_cur = s_hist + 2 * S;
+  const bool direct = HIST && a.direct_keys != nullptr;  // (grid-uniform)
   if constexpr (HIST) {
     for (int t = threadIdx.x; t < S; t += blockDim.x) s_hist[t] = 0;
+    if (direct) for (int t = threadIdx.x; t < S; t += blockDim.x) s_cur[t] = 0;
     __syncthreads();
   }
   int32_t radius_out = 0;
+  float depth_out = 0.f;
   uint32_t touched = 0;
   uint32_t touched_ref = 0;  // tiles of the reference's 3-sigma rect (what ITS num_rendered counts, rasterizer_impl.cu:280-284)
   int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
@@ -348,6 +355,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
           g.rgb[3 * (size_t)idx + 2] = fmaxf(res.z, 0.f);
         }
         g.depths[idx] = view_z;
+        depth_out = view_z;
         g.rec[2 * (size_t)idx] = make_float4(px, py, conx, cony);  // view-local pixel coordinates
         g.rec[2 * (size_t)idx + 1] = make_float4(conz, opacity, hx, hy);
         radius_out = (int32_t)my_radius;
@@ -418,7 +426,23 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(FwdPreArgs a,
     uint32_t* __restrict__ row = a.blk_base + (size_t)blk * S;
     for (int t = threadIdx.x; t < S; t += blockDim.x) {
       const uint32_t c = s_hist[t];
-      if (c) row[t] = atomicAdd(&a.tile_hist[t], c);
+      if (c) {
+        const uint32_t base = atomicAdd(&a.tile_hist[t], c);
+        row[t] = base;  // (kept in direct mode too: a later re-binning into ANOTHER workspace -- the capacity retry -- scatters)
+        if (direct) s_base[t] = base;
+      }
+    }
+    if (direct) {
+      // ... and write the keys right away: tile t's slice starts at t * direct_stride whatever the other tiles hold (a tile
+      // holds each Gaussian of its view at most once: the slice cannot overflow), so no prefix over the tiles is needed and
+      // the bin scatter kernel's work is done here, on registers that still hold the rect and the depth
+      __syncthreads();
+      const uint64_t key = ((uint64_t)__float_as_uint(depth_out) << 32) | (uint32_t)idx;
+      for (int y = ry0; y < ry1; y++)
+        for (int x = rx0; x < rx1; x++) {
+          const int t = y * a.tiles_x + x;
+          a.direct_keys[(size_t)t * a.direct_stride + s_base[t] + atomicAdd(&s_cur[t], 1u)] = key;
+        }
     }
   }
 }
@@ -456,7 +480,7 @@ hipError_t launch_preprocess_fwd(const FwdPreArgs& a, const GeomView& g, int32_t
     b.zero_blocks = b.zero_ptr ? (int)std::min<size_t>(128, (b.zero_f4 + 16383) / 16384) : 0;
     const int pb = pre_block((size_t)a.Pg);
     hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(a.V * ((a.Pg + pb - 1) / pb) + 1 + b.zero_blocks),
-                       dim3(pb), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V, s, b, g, radii);
+                       dim3(pb), sizeof(uint32_t) * (size_t)a.tiles_x * a.tiles_y * a.V * (a.direct_keys ? 3 : 1), s, b, g, radii);
   } else
     hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(a.V * ((a.Pg + 255) / 256)), dim3(256), 0, s, a, g, radii);
   return hipGetLastError();

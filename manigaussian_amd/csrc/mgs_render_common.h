@@ -37,7 +37,7 @@ __device__ __forceinline__ f32x2 exp_ocml_unclamped2(f32x2 x) {
 // EVERY kernel that takes the pair's two decisions (power > 0 -> skip, alpha < 1/255 -> skip) evaluates it through these
 // functions: the forward and every form of the backward must round it identically, or a pair within an ulp of a threshold is
 // blended by one and skipped by the other (the transmittances and suffix sums of the backward are then those of another
-// blend).  The roundings are THE REFERENCE KERNELS' as this toolchain compiles them (round 6; oracle/Makefile's build, read off
+// blend).  The roundings are THE REFERENCE KERNELS' as this toolchain compiles them (round 6; the test-only hipcc build of its sources, read off
 // the ISA of renderCUDA forward and backward at feature widths 3, 8 and 32 -- the same everywhere): the two squares are packed
 // by the vectoriser and therefore NOT contracted,
 //     t = ((dx cx) dx) + ((dy cz) dy)          v_pk_mul, v_pk_mul, v_add      (five roundings)

@@ -53,7 +53,7 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
                       size_t surv_stride, uint2* __restrict__ nsurv, float* __restrict__ final_T,
                       uint32_t* __restrict__ last_chunk, float* __restrict__ out_color, float* __restrict__ out_feat,
                       uint32_t* __restrict__ round_base, uint32_t pool, uint32_t* __restrict__ flags, int nblocks,
-                      uint64_t* host_status, uint32_t status_tag) {
+                      uint64_t* host_status, uint32_t status_tag, unsigned long long* hs_fail_mark) {
   static_assert(CHS == 64, "a chunk is two 32-lane groups of the Gaussian-major backward");
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int NCH = F + 3;
@@ -90,6 +90,10 @@ coop_fwd_pairs_kernel(RenderArgs r, const uint2* __restrict__ ranges, const uint
   __shared__ uint32_t rb_hist[RBH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: tell the compiler (scalar branches)
+  // direct binning (no bin scatter launch): ImgView::ready[1], the preprocess's "a workgroup gave up waiting" mark, was read by
+  // every workgroup of the bucket rank, the launch before this one; cleared here so that a replayed HIP graph -- same buffer,
+  // same nonce -- does not see a stale failure (with a scatter launch the bucket rank clears it: nullptr here)
+  if (blockIdx.x == 0 && tid == 0 && hs_fail_mark) *hs_fail_mark = 0ull;
   const int pr = w >> 1, hh = w & 1;         // my pair; my half block (pixel rows 4 hh .. 4 hh + 3)
   const int k_ = lane >> 5, pl_ = lane & 31; // my entry parity; my pixel inside the half block
   int tile, sub;
@@ -622,7 +626,7 @@ static hipError_t dense_F(const RenderArgs& r, const BinView& b, const ImgView& 
   hipLaunchKernelGGL((coop_fwd_pairs_kernel<F, FAST, EXACT, NW, CHUNK, TWO>), dim3(grid), dim3(NW * 64), 0, s, r,      \
                      im.ranges, b.point_list, cv.T_end, cv.T_mid, cv.last_pos, cv.partial, cv.surv,                   \
                      cv.surv_stride, cv.nsurv, im.final_T, cv.last_chunk, oc, of, cv.round_base, cv.pool, im.flags,   \
-                     4 * T, st.host, st.tag)
+                     4 * T, st.host, st.tag, (im.direct_keys && im.ready) ? im.ready + 1 : nullptr)
 #define MGS_CFD(FAST, EXACT)                                                                                          \
   do {                                                                                                                \
     if constexpr (F > 32) MGS_CFD_(FAST, EXACT, 8, false);          /* 256 registers per lane */                     \

@@ -668,7 +668,9 @@ py::object rasterize(const at::Tensor& means3D, const at::Tensor& means2D, const
   clk.lap(SG_SIZES);
   // ONE allocation for the three opaque workspaces [geom | img | binning] (each a multiple of 256 bytes)
   if (!worst) {
-    bb = mgs_binning_bytes2((int)cap, (int)pool, (int)W, (int)H, (int)F);
+    // (+ room for the forward preprocess to write the tile keys itself: no bin scatter launch, include/mgsplat.h
+    //  mgs_binning_direct_extra; a worst-case capacity, above, covers them by itself)
+    bb = up256(mgs_binning_bytes2((int)cap, (int)pool, (int)W, (int)H, (int)F)) + mgs_binning_direct_extra((int)P, 1, (int)W, (int)H);
     ws = at::empty({(int64_t)(gb + ib + bb)}, u8);
   }
   at::Tensor out_color, out_feat;

@@ -105,7 +105,9 @@ class _RasterizeViews(torch.autograd.Function):
             handle = 0
             binning = _EMPTY
             while P > 0:
-                binning = torch.empty((L.mgs_views_binning_bytes2(cap, pool, W, H, F, V),), **u8)
+                # (+ room for the preprocess to write the tile keys itself: no bin scatter launch, include/mgsplat.h)
+                binning = torch.empty((((L.mgs_views_binning_bytes2(cap, pool, W, H, F, V) + 255) & ~255) +
+                                       (0 if cap == cap_worst else L.mgs_binning_direct_extra(P, V, W, H)),), **u8)
                 if lazy and cannot_overflow and want and cap == cap_worst:
                     _state.hold(st.index, worst_bytes, binning)
                 _C._fill_args(a, P=P, D=int(s0.sh_degree), M=M, F=F, W=W, H=H, tanfovx=0.0, tanfovy=0.0,

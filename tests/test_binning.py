@@ -15,16 +15,21 @@ from manigaussian_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _lists(d, cam, W, H, F):
-    """Run a blocking forward through the reference-shaped entry point; return (ranges [T,2], keys_unsorted, point_list)."""
+def _lists(d, cam, W, H, F, blocking=True):
+    """Run a forward through the reference-shaped entry point; return (ranges [T,2], keys_unsorted, point_list).  blocking = False:
+    the package-default path (worst-case workspace, nothing waited for: the capacity covers the keys of the direct binning)."""
     dev = torch.device("cuda:0")
     kw = syn.camera_settings_kwargs(cam, 1, F > 0, bg=(0.0, 0.0, 0.0), device=dev)
     e = torch.Tensor([])
     out = _C._forward(kw["bg"], d["means3D"], e, d["language_feature"] if F else e, d["opacities"], d["scales"], d["rotations"],
                       1.0, e, kw["viewmatrix"], kw["projmatrix"], kw["tanfovx"], kw["tanfovy"], H, W, d["shs"], 1,
-                      kw["campos"], False, False, F > 0, False, blocking=True)
+                      kw["campos"], False, False, F > 0, False, blocking=blocking)
     handle, color, feat, radii, geom, binning, img = out[:7]
     torch.cuda.synchronize()
+    if img.numel() == 0:  # the package-default path: ONE allocation [geom | img | binning], handed out as the geometry buffer
+        a, base = handle.a, handle.a.geom
+        img = geom[a.img - base:a.img - base + a.img_bytes]
+        binning = geom[a.binning - base:a.binning - base + a.binning_bytes]
     L = _lib.lib()
     ku, pl, rg = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
     cap = ctypes.c_int32()
@@ -37,6 +42,15 @@ def _lists(d, cam, W, H, F):
     keys = b[ku.value:ku.value + 8 * n].view(np.uint64)
     plist = b[pl.value:pl.value + 4 * n].view(np.uint32)
     ranges = im[rg.value:rg.value + 8 * T].view(np.uint32).reshape(T, 2)
+    # "direct" binning: the forward preprocess wrote the keys itself, tile t's slice at stride * t (no bin scatter launch)
+    dk, stride = ctypes.c_size_t(), ctypes.c_int32()
+    _lib.check(L.mgs_debug_direct_keys(ctypes.byref(handle.a), 0, ctypes.byref(dk), ctypes.byref(stride)), "direct_keys")
+    _lists.direct = stride.value > 0
+    if stride.value > 0:
+        strided = b[dk.value:dk.value + 8 * T * stride.value].view(np.uint64)
+        keys = np.zeros(max(n, int(ranges[-1][1])), np.uint64)
+        for t, (lo, hi) in enumerate(ranges):
+            keys[int(lo):int(hi)] = strided[t * stride.value:t * stride.value + int(hi) - int(lo)]
     return ranges, keys, plist, int(handle), color
 
 
@@ -103,9 +117,15 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", list(CASES))
-@pytest.mark.parametrize("bin_mode", [2, 1], ids=["bucket_rank", "segment_sort_rank_merge"])
+@pytest.mark.parametrize("bin_mode", [2, -2, 1], ids=["bucket_rank_keys_by_the_preprocess", "bucket_rank_keys_by_the_scatter_launch",
+                                                      "segment_sort_rank_merge"])
 def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mode):
+    """(bin_mode 2, the default, has the forward preprocess write the keys itself wherever the workspace has room for tiles x P of
+    them -- the package-default call of this test: a worst-case workspace; -2 = the same call with MgsOptions.dbg & 32768: the bin
+    scatter launch writes them, as for workspaces without that room; the segment sort runs behind a blocking call.)"""
     case = CASES[name]
+    direct_off = bin_mode == -2
+    bin_mode = abs(bin_mode)
     if bin_mode == 1 and case["P"] > 20000 and case["W"] == 16:
         pytest.skip("the segment sort's one-tile long lists are covered by test_gpu_parity (seg 4096)")
     dev = torch.device("cuda:0")
@@ -125,14 +145,18 @@ def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mo
         d["scales"][: case["same"]] = 0.01
     if case.get("plane"):
         _plane(d, cam, torch.arange(case["plane"], device=dev), 1.6, 0.02)
-    old = {k: _lib.get_option(k) for k in ("bin_mode", "tight_bins")}
+    old = {k: _lib.get_option(k) for k in ("bin_mode", "tight_bins", "dbg")}
     try:
         _lib.set_option("bin_mode", bin_mode)
+        _lib.set_option("dbg", 32768 if direct_off else 0)
         for tight in (0, 1):
             _lib.set_option("tight_bins", tight)
-            ranges, keys, plist, R_ref, color = _lists(d, cam, W, H, 3)
+            ranges, keys, plist, R_ref, color = _lists(d, cam, W, H, 3, blocking=bin_mode != 2)
             n = _check_order(ranges, keys, plist)
             assert n > 0 and torch.isfinite(color).all()
+            T = ((W + 15) // 16) * ((H + 15) // 16)
+            if bin_mode == 2 and (direct_off or P * T <= (16 << 20)):  # (beyond 16 M keys only a worst-case capacity has the room)
+                assert _lists.direct == (not direct_off), "which kernel wrote the keys"
             if case.get("exact") and tight == 0:
                 assert n == P, f"the one tile's slice should hold exactly {P} keys, holds {n}"
             if tight == 0:
