@@ -277,7 +277,7 @@ KERNELS_BUCKET = [k for k in KERNELS_SEGSORT if k[0] not in ("bin_segsort", "bin
 KERNELS_BUCKET.insert(2, ("bin_segsort", "bin_bucket_emit_kernel", "K5'' bucket rank + emit (one launch; stage slot of the segment sort)"))
 
 
-def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk, bucket=True):
+def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk, bucket=True, direct=False):
     """HBM bytes ONE launch of each kernel has to move in THIS dataflow, every array once: P Gaussians, V views
     per launch (Pv = V P virtual Gaussians), nvis = sum over the views of Gaussians with radii > 0, R = (Gaussian, tile)
     instances, inc = (8x8 block, Gaussian) incidences of the chunks some pixel visited, pixel_chunks = (pixel, 64-survivor chunk)
@@ -290,10 +290,13 @@ def model_bytes(P, V, M, F, npix, T, R, nvis, inc, pixel_chunks, nblk, bucket=Tr
     state = pixel_chunks * 4 * (3 + F + 3)     # per (pixel, chunk): partial sums, T_end, T_mid, last_pos
     ncol = Pv if M else P                      # dL_dcolors rows: per (view, Gaussian) with SH colours
     zero = 4 * (8 * Pv + 3 * ncol + F * P)     # the backward's accumulator block, zeroed by the forward preprocess
+    # direct binning (round 6): the preprocess writes the keys itself (and still its reservation rows, for a later
+    # re-binning into another workspace); no scatter launch; the bucket rank reads the tile histogram
     return {
-        "preprocess_fwd": Pv * 12 + nvis * (28 + 4 + 12 * M) + Pv * 16 + nvis * (4 + 32 + 12 + 24 + 1) + zero,
-        "bin_scatter": Pv * 12 + nblk * T * 4 + R * 8,
-        "bin_segsort": (R * 8 + R * 4) if bucket else (R * 8 + R * 8),   # bucket rank: keys in, sorted ids out
+        "preprocess_fwd": Pv * 12 + nvis * (28 + 4 + 12 * M) + Pv * 16 + nvis * (4 + 32 + 12 + 24 + 1) + zero +
+                          ((nblk * T * 4 + R * 8) if direct else 0),
+        "bin_scatter": 0 if direct else Pv * 12 + nblk * T * 4 + R * 8,
+        "bin_segsort": (R * 8 + R * 4 + (T * 4 if direct else 0)) if bucket else (R * 8 + R * 8),   # bucket rank: keys in, sorted ids out
         "bin_merge": 0 if bucket else (R * 8 + R * 4),
         "render_fwd": R * 4 + nvis * rec + inc * 4 + state + npix * (4 * (3 + F) + 8),
         "render_bwd": inc * 4 + nvis * rec + state + npix * (4 * (3 + F) + 8) + nvis * (32 + 12 + 4 * F),
@@ -751,10 +754,12 @@ def main():
         value = P * renders_total * steps / elapsed  # whole job: every render of every rank
         npix = W * H * launch_views  # pixels one launch covers
         T_tiles = ((W + 15) // 16) * ((H + 15) // 16) * launch_views
-        nblk = launch_views * ((P + 1023) // 1024)
+        pre_block = 512 if P <= 131072 else 1024  # (csrc/mgs_common.h pre_block())
+        nblk = launch_views * ((P + pre_block - 1) // pre_block)
         bucket = _lib.get_option("bin_mode") == 2 and T_tiles <= 4096
-        KERNELS = KERNELS_BUCKET if bucket else KERNELS_SEGSORT
-        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk, bucket)
+        direct = bucket and prof.get("bin_scatter", (0.0, 0))[1] == 0  # no scatter launch was timed: the preprocess wrote the keys
+        KERNELS = [k for k in KERNELS_BUCKET if not (direct and k[0] == "bin_scatter")] if bucket else KERNELS_SEGSORT
+        mb = model_bytes(P, launch_views, M, F, npix, T_tiles, R, nvis, incidences, pixel_chunks, nblk, bucket, direct)
         so_hash = lib_hash()
         cfiles = counter_files(args.config, launch_views if not deform else 1) if not deform else \
             [f"r06_sq_counters_{args.config}.json", f"r05_sq_counters_{args.config}.json", f"r04_sq_counters_{args.config}.json"]
@@ -848,7 +853,7 @@ def main():
                        "visible_gaussians_per_launch": nvis, "block_gaussian_incidences_per_launch": incidences,
                        "chunks_per_launch": chunks, "pixel_chunks_per_launch": pixel_chunks,
                        "tight_bins": _lib.get_option("tight_bins"), "fast_exp": _lib.get_option("fast_exp"),
-                       "bin_mode": _lib.get_option("bin_mode"),
+                       "bin_mode": _lib.get_option("bin_mode"), "direct_binning": bool(direct),
                        "deformation": ("DeformationField per timestep: HIP input assembly -> fp32 MLP 70->512x5->7 (torch GEMMs, "
                                        "fused HIP elementwise passes) -> HIP apply; gradients of the MLP parameters (one flat "
                                        "bucket) and of point_latent") if deform else None,
@@ -893,7 +898,7 @@ def main():
                          "frac_of_peak_by_counter_bytes": (path_traffic / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if path_traffic and rast_ms > 0 else None,
                          "survey_8d_bytes_per_step_per_gpu": s8d_path,
-                         "note": "the rasterizer's kernels (six with the bucket-rank binning, seven with segment sort + merge): model bytes (every array once, DESIGN.md 4) over the sum of "
+                         "note": "the rasterizer's kernels (five with the direct bucket-rank binning, six with a scatter launch, seven with segment sort + merge): model bytes (every array once, DESIGN.md 4) over the sum of "
                                  "their launch durations; SURVEY.md 8d's figure (per-instance atomics charged) beside it"
                                  + ("; the deformation MLP's GEMMs are MFMA work: roofline_mlp" if deform else "")},
             "roofline_check": {"all_fractions_le_1": not violations, "violations": violations or None},

@@ -418,6 +418,7 @@ static int enqueue_render(const MgsRasterArgs* a, const Options& o, int R, const
   (void)radii;
   for (int k = 0; k < 3; k++) {
     if (k == 2 && bucket_rank(o, T)) break;  // (the bucket rank of stage 1 wrote the sorted ids)
+    if (k == 0 && bucket_rank(o, T) && im.direct_keys) continue;  // (direct binning: the preprocess wrote the keys, no scatter launch)
     StageTimer t(ST_BIN_SCATTER + k, stream);
     MGS_STAGE(launch_bin_segsort(k, lds, bucket_rank(o, T), g, b, im, a->P, 1, bs.cap, tiles_x, tiles_y, o.seg, o.dbg, status, stream),
               "binning", a->debug, stream);
@@ -810,6 +811,7 @@ int mgs_rasterize_forward_views(const MgsRasterArgs* a, int32_t V, const MgsView
   const StatusSink status = {host_status, a->status_tag};
   for (int k = 0; k < 3; k++) {
     if (k == 2 && bucket_rank(o, at.T)) break;
+    if (k == 0 && bucket_rank(o, at.T) && im.direct_keys) continue;  // (direct binning: no scatter launch)
     StageTimer t(ST_BIN_SCATTER + k, stream);
     MGS_HIP(launch_bin_segsort(k, lds, bucket_rank(o, at.T), g, b, im, a->P, V, bs.cap, at.tiles_x, at.tiles_yv * V, o.seg, o.dbg, status, stream),
             "binning (views)");

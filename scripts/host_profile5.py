@@ -128,5 +128,5 @@ with _C.use_compiled(False):
         if i % 200 == 199:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print(f"library alone through ctypes: mgs_rasterize_forward {tf / N * 1e6:.1f} us (5 launches), mgs_rasterize_backward "
+    print(f"library alone through ctypes: mgs_rasterize_forward {tf / N * 1e6:.1f} us (3 launches: preprocess with the keys, bucket rank, render; 5 in round 5), mgs_rasterize_backward "
           f"{tb / N * 1e6:.1f} us (3 launches incl. the accumulator fill) of host time per call")
