@@ -144,7 +144,7 @@ size_t mgs_binning_bytes2(int R, int chunk_pool, int W, int H, int F);  /* expli
 /* Optional: bytes to ADD to the binning workspace (behind mgs_binning_bytes2 / mgs_views_binning_bytes2) so that the forward
  * preprocess writes the tile keys itself and the bin scatter launch disappears (P Gaussians per view, V views, V = 1 for the
  * single-view calls): tiles x P keys of 8 bytes, 51 MB at 100 000 Gaussians on 128 x 128.  0: not offered for this shape (more
- * than 4 096 tiles, or more than 128 MB).  A workspace without them works as before; a capacity of at least tiles x P / 2
+ * than 4 096 tiles, or more than 512 MB).  A workspace without them works as before; a capacity of at least tiles x P / 2
  * instances (every worst-case workspace) gets the same path without them. */
 size_t mgs_binning_direct_extra(int P, int V, int W, int H);
 int mgs_chunk_pool_max(int R, int W, int H);           /* chunk records of the worst case: every chunk of every 8x8 block */

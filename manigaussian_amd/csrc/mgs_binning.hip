@@ -730,8 +730,13 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     // a preprocess workgroup gave up waiting for the zeroed tables (ready[1] == this forward's nonce): the histogram is
     // incomplete, nothing is binned, flag bit 1 tells the host why.  (The mark is read by every workgroup of this launch; the
     // render forward, next in the chain, clears it.)
-    const bool hs_failed = d.ready != nullptr && d.nonce != 0ull && d.ready[1] == d.nonce;
-    const uint32_t R = hs_failed ? 0xffffffffu : d.flags[FLAG_NUM_RENDERED];
+    // (everything this prologue reads is requested at once: the mark, the count and -- for the 64 tiles of a 128 x 128 image --
+    //  this lane's word of the histogram; read one after the other they are two dependent round trips in front of every workgroup)
+    const uint32_t x64 = (T <= 64 && lane < T) ? d.tile_hist[lane] : 0u;
+    const unsigned long long mark = (d.ready != nullptr && d.nonce != 0ull) ? d.ready[1] : 0ull;
+    const uint32_t R_dev = d.flags[FLAG_NUM_RENDERED];
+    const bool hs_failed = d.ready != nullptr && d.nonce != 0ull && mark == d.nonce;
+    const uint32_t R = hs_failed ? 0xffffffffu : R_dev;
     const bool wg0 = blockIdx.x == 0;
     if (wg0 && tid == 0) {
       if (d.ready) *d.ready = 0ull;  // the hand-shake word: "not ready" for the next launch on this buffer
@@ -749,7 +754,7 @@ __global__ void __launch_bounds__(BK_THREADS) bin_bucket_emit_kernel(int T, int 
     }
     if (tile >= T) return;
     if (T <= 64) {  // (grid-uniform) the 64 tiles of a 128 x 128 image: every wave scans the histogram in its own registers
-      const uint32_t x = lane < T ? d.tile_hist[lane] : 0u;
+      const uint32_t x = x64;
       const uint32_t incl = wave_incl_scan_add_u32(x);
       if (wg0 && wv == 0 && lane < T) d.ranges_out[lane] = make_uint2(incl - x, incl);
       rng = make_uint2(bcast_lane_u32(incl - x, tile), bcast_lane_u32(incl, tile));

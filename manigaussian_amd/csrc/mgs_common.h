@@ -82,9 +82,10 @@ struct ImgView {
 // the preprocess can write a Gaussian's keys the moment it has reserved its workgroup's slots -- no prefix over the tiles, hence
 // no scatter kernel (5 us + a kernel boundary per forward).  The bucket rank (mgs_binning.hip) reads the strided slices, scans
 // the tile histogram itself and publishes ranges and the status words.  T * Pg keys: 51 MB at BASELINE configs[2], 8 MB at
-// ManiGaussian's own shape; offered up to DIRECT_MAX_KEYS (128 MB) and whenever the caller's capacity already covers it (the
+// ManiGaussian's own shape, 410 MB for 8 views of 100 000; offered up to DIRECT_MAX_KEYS (512 MB: −1 % at 4 / 8 views; the
+// 1 GB the configs[4] shape would need buys the same 1 % and is not offered) and whenever the caller's capacity already covers it (the
 // worst-case workspaces of the default forward mode do).  Returns the keys the region must hold, 0: not applicable.
-constexpr size_t DIRECT_MAX_KEYS = (size_t)16 << 20;
+constexpr size_t DIRECT_MAX_KEYS = (size_t)64 << 20;
 inline size_t direct_keys_needed(size_t P, int V, int T) {
   const size_t v = V > 0 ? (size_t)V : 1, Pg = (P + v - 1) / v;
   return (T > 0 && T <= LDS_TILES && P > 0) ? (size_t)T * Pg : 0;

@@ -155,7 +155,7 @@ def test_every_tile_list_is_its_key_slice_in_depth_then_index_order(name, bin_mo
             n = _check_order(ranges, keys, plist)
             assert n > 0 and torch.isfinite(color).all()
             T = ((W + 15) // 16) * ((H + 15) // 16)
-            if bin_mode == 2 and (direct_off or P * T <= (16 << 20)):  # (beyond 16 M keys only a worst-case capacity has the room)
+            if bin_mode == 2 and (direct_off or P * T <= (16 << 20)):  # (larger: the worst case exceeds the budget, the call waits for the preprocess on a mark-sized workspace)
                 assert _lists.direct == (not direct_off), "which kernel wrote the keys"
             if case.get("exact") and tight == 0:
                 assert n == P, f"the one tile's slice should hold exactly {P} keys, holds {n}"
