@@ -1134,6 +1134,17 @@ def test_view_batch_equals_per_view_calls(case):
         _lib.set_option("bin_mode", _DEFAULTS["bin_mode"])
 
 
+def test_view_batch_randomised_sweep_fixed_seed():
+    """24 cases of tests/tools/fuzz_views.py (random Gaussian counts, view counts, image sizes, feature widths)."""
+    import random
+    rng = random.Random(11)
+    for _ in range(24):
+        case = dict(P=int(10 ** rng.uniform(0.0, 4.8)), F=rng.choice([3, 3, 8, 32]), V=rng.choice([2, 3, 4, 5, 8]),
+                    precomp=rng.random() < 0.2)
+        case["W"], case["H"] = rng.choice([(8, 8), (17, 33), (32, 32), (40, 72), (64, 64), (100, 52), (128, 128), (200, 120)])
+        _view_batch_equals_per_view_calls(case)
+
+
 def _view_batch_equals_per_view_calls(case):
     from manigaussian_amd import GaussianRasterizerBatch
     dev = torch.device("cuda:0")
