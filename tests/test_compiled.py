@@ -388,3 +388,41 @@ def test_safe_budget_is_charged_against_the_workspaces_live_forwards_hold(compil
         gc.collect()
         torch.cuda.synchronize()
         assert _state.held_bytes(dev.index) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compiled", [True, False], ids=["compiled", "ctypes"])
+@pytest.mark.parametrize("mode,budget_mb", [("safe", None), ("async", 0)], ids=["safe-worst-case-workspace", "async-mark-sized-workspace"])
+def test_default_paths_bin_without_a_scatter_launch(compiled, mode, budget_mb):
+    """Direct binning (csrc/mgs_common.h): on the package-default path (a worst-case workspace: its key arrays have the room) and on
+    the mark-sized workspaces of the asynchronous mode (the bindings add mgs_binning_direct_extra bytes) the forward preprocess
+    writes the tile keys itself -- the stage profile counts no bin scatter launch; with MgsOptions.dbg & 32768 it counts one per
+    forward, and the results are the same bits either way."""
+    dev, d, rast, dC, dF = _setup(16384, 3)
+    old_mode, old_budget, old_dbg = mg.set_forward_mode(mode), _state._SAFE_BYTES, _lib.get_option("dbg")
+    if budget_mb is not None:
+        mg.set_safe_workspace(budget_mb)
+    try:
+        with _C.use_compiled(compiled):
+            out = {}
+            for dbg in (0, 32768):
+                _lib.set_option("dbg", dbg)
+                for _ in range(3):  # (asynchronous mode: the first calls of a shape learn its marks on the waiting path)
+                    _step(d, rast, dC, dF)
+                    mg.check_status(dev)
+                torch.cuda.synchronize()
+                _lib.profile_read(reset=True)
+                _lib.set_option("profile", 2)
+                out[dbg] = _step(d, rast, dC, dF)
+                torch.cuda.synchronize()
+                _lib.set_option("profile", 0)
+                prof = _lib.profile_read(reset=True)
+                mg.check_status(dev)
+                assert prof["preprocess_fwd"][1] == 1 and prof["bin_segsort"][1] == 1, prof
+                assert prof["bin_scatter"][1] == (1 if dbg else 0), (dbg, prof)
+            _same(out[0], out[32768])
+    finally:
+        _lib.set_option("profile", 0)
+        _lib.set_option("dbg", old_dbg)
+        mg.set_forward_mode(old_mode)
+        _state.set_safe_bytes(old_budget)
